@@ -1,0 +1,92 @@
+"""ctypes binding of libdhw_hip.so (include/dhw.h, include/dhw_debug.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  If the
+shared object is missing or does not load, every entry point raises
+``RuntimeError`` with the build hint.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdhw_hip.so")
+
+DHW_F32, DHW_BF16, DHW_F16, DHW_F64 = 0, 1, 2, 3
+PREC_BF16, PREC_F32 = 0, 1
+
+
+class DhwDims(C.Structure):
+    _fields_ = [("num_layers", C.c_int), ("c1", C.c_int), ("c2", C.c_int), ("c3", C.c_int),
+                ("max_B", C.c_int), ("max_L", C.c_int), ("max_Lt", C.c_int), ("S", C.c_int),
+                ("precision", C.c_int)]
+
+
+class DhwError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdhw_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/dhw.h and include/dhw_debug.h declare: (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "dhw_create": (C.c_int, [C.POINTER(_P), C.POINTER(DhwDims), C.c_int]),
+    "dhw_load": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "dhw_finalize": (C.c_int, [_P]),
+    "dhw_num_keys": (C.c_int, [_P]),
+    "dhw_key_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "dhw_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "dhw_sample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, C.c_int64, _P, _P]),
+    "dhw_schedule": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "dhw_work": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dhw_last_error": (C.c_char_p, [_P]),
+    "dhw_version": (C.c_char_p, []),
+    "dhw_destroy": (None, [_P]),
+    "dhw_debug_read": (C.c_int64, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
+    "dhw_profile_enable": (C.c_int, [_P, C.c_int]),
+    "dhw_profile_reset": (C.c_int, [_P]),
+    "dhw_profile_count": (C.c_int, [_P]),
+    "dhw_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dhw_set_graph": (C.c_int, [_P, C.c_int]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes library; raise loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950). There is no fallback path.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"failed to load {LIB_PATH}: {e}. There is no fallback path.") from e
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(l, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = l
+    return l
+
+
+def check(code: int, handle=None):
+    if code < 0:
+        msg = lib().dhw_last_error(handle)
+        raise DhwError(code, msg.decode() if msg else "?")
+    return code
+
+
+def schedule(T: int = 60):
+    """(beta[T], alpha_bar[T]) as numpy fp32 — host-only, works without a GPU."""
+    import numpy as np
+    beta = np.zeros(T, np.float32)
+    alpha = np.zeros(T, np.float32)
+    check(lib().dhw_schedule(T, beta.ctypes.data_as(C.POINTER(C.c_float)), alpha.ctypes.data_as(C.POINTER(C.c_float))))
+    return beta, alpha

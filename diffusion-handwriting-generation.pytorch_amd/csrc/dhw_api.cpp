@@ -1,0 +1,1253 @@
+// dhw_api.cpp — host side of libdhw_hip.so: the C-ABI of include/dhw.h.
+//
+// Owns: the state_dict intake (strict, by key name), weight repacking into
+// MFMA-fragment order, the sigma-FiLM table, PE·W position-bias tables, the
+// activation workspace, the denoiser launch sequence (== DiffusionModel.forward,
+// reference model.py:121-182) and the T-step sampler (== inference.py:80-96)
+// with hipGraph replay.  No torch types, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dhw.h"
+#include "../../include/dhw_debug.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+constexpr int SIG = 32, SIG_HID = 2048, VOCAB = 73, STYLE_CH = 256;
+constexpr int SLACK_ROWS = 64;   // every activation buffer is over-allocated so tile over-reads stay in bounds
+
+std::string g_err;
+
+struct KeySpec { std::string key; std::vector<int64_t> shape; };
+
+// ---------------------------------------------------------------- state_dict inventory (mirrors spec.py)
+void add_linear(std::vector<KeySpec>& s, const std::string& n, int cin, int cout) {
+  s.push_back({n + ".weight", {cout, cin}});
+  s.push_back({n + ".bias", {cout}});
+}
+void add_conv(std::vector<KeySpec>& s, const std::string& n, int cin, int cout) {
+  s.push_back({n + ".weight", {cout, cin, 3}});
+  s.push_back({n + ".bias", {cout}});
+}
+void add_affine(std::vector<KeySpec>& s, const std::string& n, int c) {
+  add_linear(s, n + ".gamma_emb", SIG, c);
+  add_linear(s, n + ".beta_emb", SIG, c);
+}
+void add_convblock(std::vector<KeySpec>& s, const std::string& n, int cin, int cout) {
+  add_affine(s, n + ".affine1", cout / 2);
+  add_affine(s, n + ".affine2", cout);
+  add_affine(s, n + ".affine3", cout);
+  add_conv(s, n + ".conv_skip", cin, cout);
+  add_conv(s, n + ".conv1", cin, cout / 2);
+  add_conv(s, n + ".conv2", cout / 2, cout);
+  add_linear(s, n + ".fc", cout, cout);
+}
+void add_mha(std::vector<KeySpec>& s, const std::string& n, int d) {
+  for (const char* w : {".wq", ".wk", ".wv", ".dense"}) add_linear(s, n + w, d, d);
+}
+void add_enclayer(std::vector<KeySpec>& s, const std::string& n, int dinp, int d) {
+  add_linear(s, n + ".text_dense", dinp, d);
+  add_linear(s, n + ".ffn.1", d, 2 * d);
+  add_linear(s, n + ".ffn.3", 2 * d, d);
+  add_mha(s, n + ".mha", d);
+  add_mha(s, n + ".mha2", d);
+  for (int k = 0; k < 4; ++k) add_affine(s, n + ".affine" + std::to_string(k), d);
+}
+std::vector<KeySpec> build_spec(int nl, int c1, int c2, int c3) {
+  std::vector<KeySpec> s;
+  const int dt = 2 * c2;
+  add_linear(s, "input_dense", 2, c1);
+  add_linear(s, "sigma_ffn.1", 1, SIG_HID);
+  add_linear(s, "sigma_ffn.3", SIG_HID, c1 / 4);
+  add_convblock(s, "enc1", c1, c1);
+  add_convblock(s, "enc2", c1, c2);
+  add_enclayer(s, "enc3", dt, c2);
+  add_convblock(s, "enc4", c2, c3);
+  add_enclayer(s, "enc5", dt, c3);
+  add_conv(s, "skip_conv1", c1, c2);
+  add_conv(s, "skip_conv2", c2, c3);
+  add_conv(s, "skip_conv3", c3, dt);
+  const std::string t = "text_style_model";
+  s.push_back({t + ".emb.weight", {VOCAB, dt}});
+  add_linear(s, t + ".style_ffn.1", STYLE_CH, 4 * c2);
+  add_linear(s, t + ".style_ffn.3", 4 * c2, dt);
+  add_linear(s, t + ".text_ffn.1", dt, 2 * dt);
+  add_linear(s, t + ".text_ffn.3", 2 * dt, dt);
+  add_mha(s, t + ".mha", dt);
+  for (int k = 1; k <= 4; ++k) add_affine(s, t + ".affine" + std::to_string(k), dt);
+  add_linear(s, "att_dense", 2 * c1, dt);
+  for (int i = 0; i < nl; ++i) add_enclayer(s, "att_layers." + std::to_string(i), dt, dt);
+  add_convblock(s, "dec3", dt, c3);
+  add_convblock(s, "dec2", c3, c2);
+  add_convblock(s, "dec1", c2, c1);
+  add_linear(s, "output_dense", c1, 2);
+  add_linear(s, "pen_lifts_dense.0", c1, 1);
+  return s;
+}
+
+// ---------------------------------------------------------------- small utilities
+uint16_t f2bf(float f) {   // round-to-nearest-even; NaN stays NaN
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+float h2f(uint16_t h) {   // IEEE half -> float
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+  float v;
+  if (e == 0) v = std::ldexp((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = std::ldexp((float)(m | 1024), (int)e - 25);
+  return s ? -v : v;
+}
+
+struct ProfRec { int label; hipEvent_t a, b; double flops, bytes; };
+struct ProfAgg { std::string label; double ms = 0, flops = 0, bytes = 0; int64_t n = 0; };
+
+struct Tap { void* p; int rows; int cols; bool f32; };
+
+// one ConvBlock / EncoderLayer worth of packed weights
+struct ConvBlockW {
+  void *w_c1, *w_c2, *w_fc, *w_skip;
+  float *b_c1, *b_c2, *b_fc, *b_skip;
+  int cin, cout, f1, f2, f3;   // FiLM offsets
+};
+struct EncLayerW {
+  void *w_td, *w_kv1, *w_q1, *w_d1, *w_qkv2, *w_d2, *w_f1, *w_f2;
+  float *b_td, *b_kv1, *b_q1, *b_d1, *b_qkv2, *b_d2, *b_f1, *b_f2;
+  float *pb_k1, *pb_q1, *pb_qk2;   // PE·W tables
+  int d, heads, f0, f1, f2, f3;
+  float pos_factor;
+};
+
+}  // namespace
+
+struct dhw_handle {
+  dhw_dims dims{};
+  int device = 0;
+  int prec = 0;
+  size_t es = 2;
+  std::string err;
+  std::vector<KeySpec> spec;
+  std::map<std::string, int> key_index;
+  std::vector<std::vector<float>> host_w;
+  std::vector<char> loaded;
+  bool packed = false;
+  std::vector<void*> allocs;
+
+  // FiLM
+  std::map<std::string, int> film_off;
+  int film_tot = 0;
+  float *d_film_w = nullptr, *d_film_b = nullptr;
+  float *d_sig32 = nullptr, *d_film = nullptr, *d_sigma_in = nullptr;
+  float *d_sig32_T = nullptr, *d_film_T = nullptr;
+  int film_T_cap = 0;
+
+  // small fp32 weights
+  float *sg_w1, *sg_b1, *sg_w2, *sg_b2, *in_w, *in_b, *out_w, *out_b, *pen_w, *pen_b, *emb;
+
+  ConvBlockW enc1, enc2, enc4, dec3, dec2, dec1;
+  std::vector<EncLayerW> el;   // enc3, enc5, att_layers...
+  void *w_sf1, *w_sf3, *w_q8, *w_kv8, *w_d8, *w_tf1, *w_tf3, *w_attd, *w_sk1, *w_sk2, *w_sk3;
+  float *b_sf1, *b_sf3, *b_q8, *b_kv8, *b_d8, *b_tf1, *b_tf3, *b_attd, *b_sk1, *b_sk2, *b_sk3;
+  int f_ts1, f_ts2, f_ts3, f_ts4;
+
+  // workspace
+  std::map<std::string, void*> buf;
+  std::map<std::string, Tap> taps;
+  int lpadT = 0, lpadS = 0, lpadX[3] = {0, 0, 0};
+  float* d_xt = nullptr;
+  float* d_eps = nullptr;
+  float* d_pen = nullptr;
+
+  // profiling
+  bool prof = false;
+  std::vector<std::string> prof_labels;
+  std::vector<ProfRec> prof_recs;
+  std::vector<ProfAgg> prof_agg;
+
+  // graph cache for dhw_sample
+  bool use_graph = true;
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<uint64_t> graph_key;
+  uint64_t* d_seed = nullptr;   // [seed, first_sample] read by the noise kernels
+  float* d_sigma_T = nullptr;
+  int film_T_ready = 0;         // T for which d_film_T currently holds the FiLM table (0 = none)
+
+  int last_B = 0, last_L = 0, last_Lt = 0;
+};
+
+namespace {
+
+int fail(dhw_handle* h, int code, const char* fmt, ...) {
+  char tmp[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  if (h) h->err = tmp;
+  g_err = tmp;
+  return code;
+}
+
+#define HIPCK(h, call)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail(h, DHW_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+int dev_alloc(dhw_handle* h, void** p, size_t bytes, bool zero = true) {
+  HIPCK(h, hipMalloc(p, bytes ? bytes : 16));
+  h->allocs.push_back(*p);
+  if (zero) HIPCK(h, hipMemset(*p, 0, bytes ? bytes : 16));
+  return 0;
+}
+
+const std::vector<float>& W(dhw_handle* h, const std::string& key) { return h->host_w[h->key_index.at(key)]; }
+
+int upload_f32(dhw_handle* h, const std::vector<float>& v, float** out) {
+  int rc = dev_alloc(h, (void**)out, v.size() * 4, false);
+  if (rc) return rc;
+  HIPCK(h, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Pack a row-major weight matrix Wf[N][K] into MFMA-fragment order
+// [N/16][K/32][64 lanes][8]: lane l holds Wf[nt*16 + (l&15)][kc*32 + 8*(l>>4) + j].
+int upload_packed(dhw_handle* h, const std::vector<float>& wf, int N, int K, void** out) {
+  if (N % 16 || K % 32 || (size_t)N * K != wf.size()) return fail(h, DHW_ERR_ARG, "pack: bad shape %d x %d", N, K);
+  const size_t n = (size_t)N * K;
+  std::vector<float> pk(n);
+  size_t o = 0;
+  for (int nt = 0; nt < N / 16; ++nt)
+    for (int kc = 0; kc < K / 32; ++kc)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) pk[o++] = wf[(size_t)(nt * 16 + (l & 15)) * K + kc * 32 + 8 * (l >> 4) + j];
+  int rc = dev_alloc(h, out, n * h->es, false);
+  if (rc) return rc;
+  if (h->prec == PREC_F32) {
+    HIPCK(h, hipMemcpy(*out, pk.data(), n * 4, hipMemcpyHostToDevice));
+  } else {
+    std::vector<uint16_t> b(n);
+    for (size_t i = 0; i < n; ++i) b[i] = f2bf(pk[i]);
+    HIPCK(h, hipMemcpy(*out, b.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// Conv1d weight [Cout][Cin][3] -> GEMM matrix [Cout][tap*Cin + c]
+std::vector<float> conv_flat(const std::vector<float>& w, int cout, int cin) {
+  std::vector<float> f((size_t)cout * cin * 3);
+  for (int n = 0; n < cout; ++n)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < 3; ++t) f[(size_t)n * cin * 3 + t * cin + c] = w[((size_t)n * cin + c) * 3 + t];
+  return f;
+}
+std::vector<float> vcat(std::initializer_list<const std::vector<float>*> vs) {
+  std::vector<float> r;
+  for (auto v : vs) r.insert(r.end(), v->begin(), v->end());
+  return r;
+}
+
+// Sinusoidal table PE[pos][dim] exactly as attention.py:15-23 evaluates it in fp32.
+std::vector<float> pe_table(int n, int dim, float pos_factor) {
+  const int half = dim / 2;
+  const float negc = (float)(-(std::log(10000.0) / (half - 1)));
+  std::vector<float> pe((size_t)n * dim);
+  for (int j = 0; j < half; ++j) {
+    const float f = expf((float)j * negc);
+    for (int t = 0; t < n; ++t) {
+      const float e = ((float)t * f) * pos_factor;
+      pe[(size_t)t * dim + j] = sinf(e);
+      pe[(size_t)t * dim + half + j] = cosf(e);
+    }
+  }
+  return pe;
+}
+// posb[pos][n] = sum_k PE[pos][k] * Wm[n][k]   (Wm: [N][dim] row-major)
+std::vector<float> pe_times_w(const std::vector<float>& pe, int n, int dim, const std::vector<float>& wm, int N) {
+  std::vector<float> r((size_t)n * N);
+  for (int t = 0; t < n; ++t)
+    for (int o = 0; o < N; ++o) {
+      double a = 0;
+      const float* p = &pe[(size_t)t * dim];
+      const float* w = &wm[(size_t)o * dim];
+      for (int k = 0; k < dim; ++k) a += (double)p[k] * (double)w[k];
+      r[(size_t)t * N + o] = (float)a;
+    }
+  return r;
+}
+
+int pack_convblock(dhw_handle* h, const std::string& n, int cin, int cout, ConvBlockW& cb) {
+  cb.cin = cin;
+  cb.cout = cout;
+  int rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, n + ".conv1.weight"), cout / 2, cin), cout / 2, 3 * cin, &cb.w_c1))) return rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, n + ".conv2.weight"), cout, cout / 2), cout, 3 * (cout / 2), &cb.w_c2))) return rc;
+  if ((rc = upload_packed(h, W(h, n + ".fc.weight"), cout, cout, &cb.w_fc))) return rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, n + ".conv_skip.weight"), cout, cin), cout, 3 * cin, &cb.w_skip))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".conv1.bias"), &cb.b_c1))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".conv2.bias"), &cb.b_c2))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".fc.bias"), &cb.b_fc))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".conv_skip.bias"), &cb.b_skip))) return rc;
+  cb.f1 = h->film_off.at(n + ".affine1");
+  cb.f2 = h->film_off.at(n + ".affine2");
+  cb.f3 = h->film_off.at(n + ".affine3");
+  return 0;
+}
+
+int pack_enclayer(dhw_handle* h, const std::string& n, int d, int heads, float pf, int max_lk, EncLayerW& e) {
+  e.d = d;
+  e.heads = heads;
+  e.pos_factor = pf;
+  const int dt = 2 * h->dims.c2;
+  int rc;
+  auto& wq1 = W(h, n + ".mha.wq.weight");
+  auto& wk1 = W(h, n + ".mha.wk.weight");
+  auto& wv1 = W(h, n + ".mha.wv.weight");
+  auto& wq2 = W(h, n + ".mha2.wq.weight");
+  auto& wk2 = W(h, n + ".mha2.wk.weight");
+  auto& wv2 = W(h, n + ".mha2.wv.weight");
+  if ((rc = upload_packed(h, W(h, n + ".text_dense.weight"), d, dt, &e.w_td))) return rc;
+  if ((rc = upload_packed(h, vcat({&wk1, &wv1}), 2 * d, d, &e.w_kv1))) return rc;
+  if ((rc = upload_packed(h, wq1, d, d, &e.w_q1))) return rc;
+  if ((rc = upload_packed(h, W(h, n + ".mha.dense.weight"), d, d, &e.w_d1))) return rc;
+  if ((rc = upload_packed(h, vcat({&wq2, &wk2, &wv2}), 3 * d, d, &e.w_qkv2))) return rc;
+  if ((rc = upload_packed(h, W(h, n + ".mha2.dense.weight"), d, d, &e.w_d2))) return rc;
+  if ((rc = upload_packed(h, W(h, n + ".ffn.1.weight"), 2 * d, d, &e.w_f1))) return rc;
+  if ((rc = upload_packed(h, W(h, n + ".ffn.3.weight"), d, 2 * d, &e.w_f2))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".text_dense.bias"), &e.b_td))) return rc;
+  if ((rc = upload_f32(h, vcat({&W(h, n + ".mha.wk.bias"), &W(h, n + ".mha.wv.bias")}), &e.b_kv1))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".mha.wq.bias"), &e.b_q1))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".mha.dense.bias"), &e.b_d1))) return rc;
+  if ((rc = upload_f32(h, vcat({&W(h, n + ".mha2.wq.bias"), &W(h, n + ".mha2.wk.bias"), &W(h, n + ".mha2.wv.bias")}), &e.b_qkv2))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".mha2.dense.bias"), &e.b_d2))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".ffn.1.bias"), &e.b_f1))) return rc;
+  if ((rc = upload_f32(h, W(h, n + ".ffn.3.bias"), &e.b_f2))) return rc;
+  // (x + PE)·W = x·W + PE·W: the PE term is a per-position bias table (model.py:40-50, attention.py:15-23)
+  const auto pe_t = pe_table(h->dims.max_Lt + SLACK_ROWS, d, 1.0f);                 // text_pe_gen: pos_factor 1 (model.py:22)
+  const auto pe_x = pe_table(max_lk + SLACK_ROWS, d, pf);                           // stroke_pe_gen
+  if ((rc = upload_f32(h, pe_times_w(pe_t, h->dims.max_Lt + SLACK_ROWS, d, wk1, d), &e.pb_k1))) return rc;
+  if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, wq1, d), &e.pb_q1))) return rc;
+  if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, vcat({&wq2, &wk2}), 2 * d), &e.pb_qk2))) return rc;
+  e.f0 = h->film_off.at(n + ".affine0");
+  e.f1 = h->film_off.at(n + ".affine1");
+  e.f2 = h->film_off.at(n + ".affine2");
+  e.f3 = h->film_off.at(n + ".affine3");
+  return 0;
+}
+
+int act_alloc(dhw_handle* h, const std::string& name, long rows, int cols, bool f32 = false) {
+  void* p;
+  const size_t bytes = (size_t)(rows + SLACK_ROWS) * cols * (f32 ? 4 : h->es);
+  int rc = dev_alloc(h, &p, bytes, true);
+  if (rc) return rc;
+  h->buf[name] = p;
+  return 0;
+}
+
+int pad32(int x) { return ((x + 31) / 32) * 32; }
+
+int alloc_workspace(dhw_handle* h) {
+  const dhw_dims& d = h->dims;
+  const long B = d.max_B, L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
+  const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
+  int rc;
+#define AA(name, rows, cols) if ((rc = act_alloc(h, name, rows, cols))) return rc
+  AA("sty_in", B * S5, STYLE_CH); AA("sty_h", B * S5, 4 * c2); AA("sty_n", B * S5, dt); AA("s1", B * S5, dt);
+  AA("k8", B * S5, dt);
+  AA("t_n", B * Lt, dt); AA("t1", B * Lt, dt); AA("q8", B * Lt, dt); AA("a8", B * Lt, dt); AA("t2", B * Lt, dt);
+  AA("tf_h", B * Lt, 2 * dt); AA("text_out", B * Lt, dt);
+  h->lpadS = pad32((int)S5);
+  h->lpadT = pad32((int)Lt);
+  AA("vt8", B * dt, h->lpadS);
+  AA("x0", B * L, c1);
+  struct CB { const char* n; long rows; int cin, cout; };
+  const CB cbs[6] = {{"enc1", L, c1, c1}, {"enc2", L / 2, c1, c2}, {"enc4", L / 4, c2, c3},
+                     {"dec3", L / 4, dt, c3}, {"dec2", L / 2, c3, c2}, {"dec1", L, c2, c1}};
+  for (const CB& c : cbs) {
+    AA(std::string(c.n) + ".h1", B * c.rows, c.cout / 2);
+    AA(std::string(c.n) + ".h2", B * c.rows, c.cout);
+    if (std::string(c.n) == "dec1") { if ((rc = act_alloc(h, "dec1", B * c.rows, c.cout, true))) return rc; }
+    else AA(c.n, B * c.rows, c.cout);
+  }
+  AA("enc1.pool", B * L / 2, c1);
+  struct EL { std::string n; long rows; int dm; };
+  std::vector<EL> els = {{"enc3", L / 2, c2}, {"enc5", L / 4, c3}};
+  for (int i = 0; i < d.num_layers; ++i) els.push_back({"att_layers." + std::to_string(i), L / 8, dt});
+  h->lpadX[0] = pad32((int)(L / 2));
+  h->lpadX[1] = pad32((int)(L / 4));
+  h->lpadX[2] = pad32((int)(L / 8));
+  for (size_t i = 0; i < els.size(); ++i) {
+    const EL& e = els[i];
+    const int lp = h->lpadX[i < 2 ? i : 2];
+    AA(e.n + ".tl", B * Lt, e.dm); AA(e.n + ".k1", B * Lt, e.dm); AA(e.n + ".vt1", B * e.dm, h->lpadT);
+    AA(e.n + ".q1", B * e.rows, e.dm); AA(e.n + ".a1", B * e.rows, e.dm); AA(e.n + ".x2", B * e.rows, e.dm);
+    AA(e.n + ".qk2", B * e.rows, 2 * e.dm); AA(e.n + ".vt2", B * e.dm, lp); AA(e.n + ".a2", B * e.rows, e.dm);
+    AA(e.n + ".x3", B * e.rows, e.dm); AA(e.n + ".f", B * e.rows, 2 * e.dm); AA(e.n, B * e.rows, e.dm);
+  }
+  AA("enc3.pool", B * L / 4, c2); AA("enc5.pool", B * L / 8, c3);
+  AA("att_dense", B * L / 8, dt);
+  AA("xd3", B * L / 4, dt); AA("xd2", B * L / 2, c3); AA("xd1", B * L, c2);
+#undef AA
+  if ((rc = dev_alloc(h, (void**)&h->d_sigma_in, B * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_sig32, B * SIG * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_film, (size_t)B * 2 * h->film_tot * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_xt, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_eps, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_pen, (size_t)(B * L + SLACK_ROWS) * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_seed, 16))) return rc;
+  return 0;
+}
+
+void build_film_layout(dhw_handle* h) {
+  int off = 0;
+  for (const KeySpec& k : h->spec) {
+    const std::string suf = ".gamma_emb.weight";
+    if (k.key.size() > suf.size() && k.key.compare(k.key.size() - suf.size(), suf.size(), suf) == 0) {
+      h->film_off[k.key.substr(0, k.key.size() - suf.size())] = off;
+      off += (int)k.shape[0];
+    }
+  }
+  h->film_tot = off;
+}
+
+// ---------------------------------------------------------------- profiling wrapper
+struct Launch {
+  dhw_handle* h;
+  hipStream_t st;
+  int rec = -1;
+  Launch(dhw_handle* h_, hipStream_t st_, const char* label, double flops = 0, double bytes = 0) : h(h_), st(st_) {
+    if (!h->prof) return;
+    int id = -1;
+    for (size_t i = 0; i < h->prof_labels.size(); ++i)
+      if (h->prof_labels[i] == label) id = (int)i;
+    if (id < 0) { id = (int)h->prof_labels.size(); h->prof_labels.push_back(label); }
+    ProfRec r{id, nullptr, nullptr, flops, bytes};
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+    h->prof_recs.push_back(r);
+    rec = (int)h->prof_recs.size() - 1;
+  }
+  ~Launch() {
+    if (rec >= 0) hipEventRecord(h->prof_recs[rec].b, st);
+  }
+};
+
+// ---------------------------------------------------------------- the denoiser launch sequence
+struct Ctx {
+  dhw_handle* h;
+  hipStream_t st;
+  int B, L, Lt, S5;
+  const float* film;   // row 0 of the FiLM table to use
+  long film_bs;        // batch stride (0 in the sampling loop)
+  int err = 0;
+};
+
+void* BUF(dhw_handle* h, const std::string& n) { return h->buf.at(n); }
+
+GemmParams gp_base(const Ctx& c, int L, int N) {
+  GemmParams p{};
+  p.nseg = 1;
+  p.B = c.B;
+  p.L = L;
+  p.N = N;
+  p.n_store = N;
+  p.film_bs = c.film_bs;
+  return p;
+}
+void set_film(const Ctx& c, GemmParams& p, int off, int mode) {
+  p.gam = c.film + off;
+  p.bet = c.film + c.h->film_tot + off;
+  p.film_mode = mode;
+}
+double gemm_flops(const GemmParams& p) {
+  double k = 0;
+  for (int s = 0; s < p.nseg; ++s) k += (double)p.seg[s].C * p.seg[s].taps;
+  return 2.0 * p.B * p.L * p.N * k;
+}
+double gemm_bytes(const dhw_handle* h, const GemmParams& p) {   // algorithmic: activations in + out once, weights once
+  double b = 0;
+  for (int s = 0; s < p.nseg; ++s) b += (double)p.B * p.L * p.seg[s].C * h->es + (double)p.N * p.seg[s].C * p.seg[s].taps * h->es;
+  b += (double)p.B * p.L * p.N * (p.out_f32 ? 4 : h->es);
+  if (p.res1) b += (double)p.B * p.L * p.N * h->es;
+  if (p.res2) b += (double)p.B * p.L * p.N * h->es / (p.res2_half ? 2 : 1);
+  if (p.pool) b += (double)p.B * p.L * p.N * h->es / 2;
+  return b;
+}
+void run_gemm(Ctx& c, const char* label, const GemmParams& p) {
+  if (c.err) return;
+  Launch l(c.h, c.st, label, gemm_flops(p), gemm_bytes(c.h, p));
+  hipError_t e = launch_gemm(c.h->prec, p, c.st);
+  if (e != hipSuccess) c.err = fail(c.h, DHW_ERR_HIP, "gemm %s: %s", label, hipGetErrorString(e));
+}
+void run_attn(Ctx& c, const char* label, const AttnParams& p) {
+  if (c.err) return;
+  Launch l(c.h, c.st, label, 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.D,
+           (double)p.B * p.H * p.D * (2.0 * p.Lq + 2.0 * p.Lk) * c.h->es);
+  hipError_t e = launch_attn(c.h->prec, p, c.st);
+  if (e != hipSuccess) c.err = fail(c.h, DHW_ERR_HIP, "attn %s: %s", label, hipGetErrorString(e));
+}
+#define RUN_SMALL(c, label, call)                                                                  \
+  do {                                                                                             \
+    if (!(c).err) {                                                                                \
+      Launch l_((c).h, (c).st, label);                                                             \
+      hipError_t e_ = (call);                                                                      \
+      if (e_ != hipSuccess) (c).err = fail((c).h, DHW_ERR_HIP, "%s: %s", label, hipGetErrorString(e_)); \
+    }                                                                                              \
+  } while (0)
+
+void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, int cols, bool f32 = false) {
+  c.h->taps[name] = Tap{BUF(c.h, bufname), rows, cols, f32};
+}
+
+// cnn.py:64-87 as three fused GEMM launches
+void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
+                void* pool) {
+  dhw_handle* h = c.h;
+  {  // h1 = SiLU(FiLM1(conv1(SiLU(x))))
+    GemmParams p = gp_base(c, L, w.cout / 2);
+    p.seg[0] = GemmSeg{x, w.w_c1, w.cin, 3, 1};
+    p.bias0 = w.b_c1;
+    set_film(c, p, w.f1, 1);
+    p.silu_out = 1;
+    p.out = BUF(h, n + ".h1");
+    run_gemm(c, "convblock.conv1", p);
+  }
+  {  // h2 = SiLU(FiLM2(conv2(h1)))
+    GemmParams p = gp_base(c, L, w.cout);
+    p.seg[0] = GemmSeg{BUF(h, n + ".h1"), w.w_c2, w.cout / 2, 3, 0};
+    p.bias0 = w.b_c2;
+    set_film(c, p, w.f2, 1);
+    p.silu_out = 1;
+    p.out = BUF(h, n + ".h2");
+    run_gemm(c, "convblock.conv2", p);
+  }
+  {  // out = FiLM3(fc(h2)) + conv_skip(x)
+    GemmParams p = gp_base(c, L, w.cout);
+    p.nseg = 2;
+    p.seg[0] = GemmSeg{BUF(h, n + ".h2"), w.w_fc, w.cout, 1, 0};
+    p.seg[1] = GemmSeg{x, w.w_skip, w.cin, 3, 0};
+    p.bias0 = w.b_fc;
+    p.bias1 = w.b_skip;
+    set_film(c, p, w.f3, 2);
+    p.out = out;
+    p.out_f32 = out_f32;
+    p.pool = pool;
+    run_gemm(c, "convblock.fc_skip", p);
+  }
+  tap(c, n, n, L, w.cout, out_f32);
+}
+
+// model.py:37-58.  The text-side projections (tl, k1, vt1) are produced by enc_layer_text.
+void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
+  dhw_handle* h = c.h;
+  const int dt = 2 * h->dims.c2;
+  {  // tl = FiLM0(LN(text_dense(SiLU(text))))
+    GemmParams p = gp_base(c, c.Lt, w.d);
+    p.seg[0] = GemmSeg{BUF(h, "text_out"), w.w_td, dt, 1, 1};
+    p.bias0 = w.b_td;
+    p.ln = 1;
+    set_film(c, p, w.f0, 1);
+    p.out = BUF(h, n + ".tl");
+    run_gemm(c, "enc.text_dense", p);
+  }
+  {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
+    GemmParams p = gp_base(c, c.Lt, 2 * w.d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".tl"), w.w_kv1, w.d, 1, 0};
+    p.bias0 = w.b_kv1;
+    p.posb = w.pb_k1;
+    p.posb_cols = w.d;
+    p.n_store = w.d;
+    p.out = BUF(h, n + ".k1");
+    p.vt = BUF(h, n + ".vt1");
+    p.vt_lpad = h->lpadT;
+    run_gemm(c, "enc.kv_text", p);
+  }
+}
+
+void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
+               void* pool) {
+  dhw_handle* h = c.h;
+  const int d = w.d;
+  {  // q1 = Wq(x + PE)
+    GemmParams p = gp_base(c, Lk, d);
+    p.seg[0] = GemmSeg{x, w.w_q1, d, 1, 0};
+    p.bias0 = w.b_q1;
+    p.posb = w.pb_q1;
+    p.posb_cols = d;
+    p.out = BUF(h, n + ".q1");
+    run_gemm(c, "enc.q_cross", p);
+  }
+  {
+    AttnParams a{};
+    a.Q = BUF(h, n + ".q1"); a.ldq = d;
+    a.K = BUF(h, n + ".k1"); a.ldk = d; a.koff = 0;
+    a.Vt = BUF(h, n + ".vt1"); a.lpad = h->lpadT;
+    a.text = text; a.ldt = c.Lt;
+    a.out = BUF(h, n + ".a1"); a.ldo = d;
+    a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = c.Lt;
+    run_attn(c, "attn.cross", a);
+  }
+  {  // x2 = FiLM1(LN(dense(a1))) + x
+    GemmParams p = gp_base(c, Lk, d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".a1"), w.w_d1, d, 1, 0};
+    p.bias0 = w.b_d1;
+    p.ln = 1;
+    set_film(c, p, w.f1, 1);
+    p.res2 = x;
+    p.out = BUF(h, n + ".x2");
+    run_gemm(c, "enc.dense_cross", p);
+  }
+  {  // q2,k2 = W(x2 + PE), v2 = Wv x2
+    GemmParams p = gp_base(c, Lk, 3 * d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".x2"), w.w_qkv2, d, 1, 0};
+    p.bias0 = w.b_qkv2;
+    p.posb = w.pb_qk2;
+    p.posb_cols = 2 * d;
+    p.n_store = 2 * d;
+    p.out = BUF(h, n + ".qk2");
+    p.vt = BUF(h, n + ".vt2");
+    p.vt_lpad = lpad;
+    run_gemm(c, "enc.qkv_self", p);
+  }
+  {
+    AttnParams a{};
+    a.Q = BUF(h, n + ".qk2"); a.ldq = 2 * d;
+    a.K = BUF(h, n + ".qk2"); a.ldk = 2 * d; a.koff = d;
+    a.Vt = BUF(h, n + ".vt2"); a.lpad = lpad;
+    a.text = nullptr;
+    a.out = BUF(h, n + ".a2"); a.ldo = d;
+    a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = Lk;
+    run_attn(c, "attn.self", a);
+  }
+  {  // x3 = FiLM2(LN(x2 + dense(a2)))
+    GemmParams p = gp_base(c, Lk, d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".a2"), w.w_d2, d, 1, 0};
+    p.bias0 = w.b_d2;
+    p.res1 = BUF(h, n + ".x2");
+    p.ln = 1;
+    set_film(c, p, w.f2, 1);
+    p.out = BUF(h, n + ".x3");
+    run_gemm(c, "enc.dense_self", p);
+  }
+  {  // f = SiLU(W1 SiLU(x3) + b1)
+    GemmParams p = gp_base(c, Lk, 2 * d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".x3"), w.w_f1, d, 1, 1};
+    p.bias0 = w.b_f1;
+    p.silu_out = 1;
+    p.out = BUF(h, n + ".f");
+    run_gemm(c, "enc.ffn1", p);
+  }
+  {  // out = FiLM3(LN(W2 f + b2 + x3))
+    GemmParams p = gp_base(c, Lk, d);
+    p.seg[0] = GemmSeg{BUF(h, n + ".f"), w.w_f2, 2 * d, 1, 0};
+    p.bias0 = w.b_f2;
+    p.res1 = BUF(h, n + ".x3");
+    p.ln = 1;
+    set_film(c, p, w.f3, 1);
+    p.out = BUF(h, n);
+    p.pool = pool;
+    run_gemm(c, "enc.ffn2", p);
+  }
+  tap(c, n + ".x2", n + ".x2", Lk, d);
+  tap(c, n + ".x3", n + ".x3", Lk, d);
+  tap(c, n, n, Lk, d);
+}
+
+// sigma-independent prefix of TextStyleEncoder (text_style.py:92-97 up to the LayerNorms; Dropout is identity in eval)
+void text_style_static(Ctx& c, const int64_t* text, const float* style) {
+  dhw_handle* h = c.h;
+  const int c2 = h->dims.c2, dt = 2 * c2;
+  RUN_SMALL(c, "cast.style", launch_cast(h->prec, style, (long)c.B * c.S5 * STYLE_CH, BUF(h, "sty_in"), c.st));
+  {
+    GemmParams p = gp_base(c, c.S5, 4 * c2);
+    p.seg[0] = GemmSeg{BUF(h, "sty_in"), h->w_sf1, STYLE_CH, 1, 1};
+    p.bias0 = h->b_sf1;
+    p.silu_out = 1;
+    p.out = BUF(h, "sty_h");
+    run_gemm(c, "style.ffn1", p);
+  }
+  {
+    GemmParams p = gp_base(c, c.S5, dt);
+    p.seg[0] = GemmSeg{BUF(h, "sty_h"), h->w_sf3, 4 * c2, 1, 0};
+    p.bias0 = h->b_sf3;
+    p.ln = 1;
+    p.out = BUF(h, "sty_n");
+    run_gemm(c, "style.ffn2_ln", p);
+  }
+  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, VOCAB, BUF(h, "t_n"), c.st));
+}
+
+// sigma-dependent part of TextStyleEncoder (text_style.py:94-104) + the per-layer text projections
+void text_style_dynamic(Ctx& c) {
+  dhw_handle* h = c.h;
+  const int c2 = h->dims.c2, dt = 2 * c2;
+  const float* g = c.film;
+  const float* bt = c.film + h->film_tot;
+  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(h, "sty_n"), c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, BUF(h, "s1"), c.st));
+  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(h, "t_n"), c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, BUF(h, "t1"), c.st));
+  {
+    GemmParams p = gp_base(c, c.Lt, dt);
+    p.seg[0] = GemmSeg{BUF(h, "t1"), h->w_q8, dt, 1, 0};
+    p.bias0 = h->b_q8;
+    p.out = BUF(h, "q8");
+    run_gemm(c, "ts.q", p);
+  }
+  {
+    GemmParams p = gp_base(c, c.S5, 2 * dt);
+    p.seg[0] = GemmSeg{BUF(h, "s1"), h->w_kv8, dt, 1, 0};
+    p.bias0 = h->b_kv8;
+    p.n_store = dt;
+    p.out = BUF(h, "k8");
+    p.vt = BUF(h, "vt8");
+    p.vt_lpad = h->lpadS;
+    run_gemm(c, "ts.kv", p);
+  }
+  {
+    AttnParams a{};
+    a.Q = BUF(h, "q8"); a.ldq = dt;
+    a.K = BUF(h, "k8"); a.ldk = dt; a.koff = 0;
+    a.Vt = BUF(h, "vt8"); a.lpad = h->lpadS;
+    a.out = BUF(h, "a8"); a.ldo = dt;
+    a.B = c.B; a.H = 8; a.D = dt / 8; a.Lq = c.Lt; a.Lk = c.S5;
+    run_attn(c, "attn.text_style", a);
+  }
+  {
+    GemmParams p = gp_base(c, c.Lt, dt);
+    p.seg[0] = GemmSeg{BUF(h, "a8"), h->w_d8, dt, 1, 0};
+    p.bias0 = h->b_d8;
+    p.res1 = BUF(h, "t1");
+    p.ln = 1;
+    set_film(c, p, h->f_ts3, 1);
+    p.out = BUF(h, "t2");
+    run_gemm(c, "ts.dense", p);
+  }
+  {
+    GemmParams p = gp_base(c, c.Lt, 2 * dt);
+    p.seg[0] = GemmSeg{BUF(h, "t2"), h->w_tf1, dt, 1, 1};
+    p.bias0 = h->b_tf1;
+    p.silu_out = 1;
+    p.out = BUF(h, "tf_h");
+    run_gemm(c, "ts.ffn1", p);
+  }
+  {
+    GemmParams p = gp_base(c, c.Lt, dt);
+    p.seg[0] = GemmSeg{BUF(h, "tf_h"), h->w_tf3, 2 * dt, 1, 0};
+    p.bias0 = h->b_tf3;
+    p.ln = 1;
+    set_film(c, p, h->f_ts4, 1);
+    p.out = BUF(h, "text_out");
+    run_gemm(c, "ts.ffn2", p);
+  }
+  tap(c, "text_style_model.style", "s1", c.S5, dt);
+  tap(c, "text_style_model.t2", "t2", c.Lt, dt);
+  tap(c, "text_style_model", "text_out", c.Lt, dt);
+  const char* names[2] = {"enc3", "enc5"};
+  for (size_t i = 0; i < h->el.size(); ++i)
+    enc_layer_text(c, i < 2 ? names[i] : "att_layers." + std::to_string(i - 2), h->el[i]);
+}
+
+// the stroke path of DiffusionModel.forward (model.py:139-182); the heads are launched by the caller
+void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
+  dhw_handle* h = c.h;
+  const dhw_dims& d = h->dims;
+  const int L = c.L, dt = 2 * d.c2;
+  RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(h, "x0"), c.st));
+  tap(c, "input_dense", "x0", L, d.c1);
+  conv_block(c, "enc1", h->enc1, BUF(h, "x0"), L, BUF(h, "enc1"), false, BUF(h, "enc1.pool"));
+  conv_block(c, "enc2", h->enc2, BUF(h, "enc1.pool"), L / 2, BUF(h, "enc2"), false, nullptr);
+  enc_layer(c, "enc3", h->el[0], BUF(h, "enc2"), L / 2, h->lpadX[0], text, BUF(h, "enc3.pool"));
+  conv_block(c, "enc4", h->enc4, BUF(h, "enc3.pool"), L / 4, BUF(h, "enc4"), false, nullptr);
+  enc_layer(c, "enc5", h->el[1], BUF(h, "enc4"), L / 4, h->lpadX[1], text, BUF(h, "enc5.pool"));
+  {
+    GemmParams p = gp_base(c, L / 8, dt);
+    p.seg[0] = GemmSeg{BUF(h, "enc5.pool"), h->w_attd, d.c3, 1, 0};
+    p.bias0 = h->b_attd;
+    p.out = BUF(h, "att_dense");
+    run_gemm(c, "att_dense", p);
+    tap(c, "att_dense", "att_dense", L / 8, dt);
+  }
+  const void* x = BUF(h, "att_dense");
+  for (int i = 0; i < d.num_layers; ++i) {
+    const std::string n = "att_layers." + std::to_string(i);
+    enc_layer(c, n, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr);
+    x = BUF(h, n);
+  }
+  struct UP { const char* name; const void* skip_in; void* w; float* b; int cin, cout, L; const void* low; const char* out; };
+  const UP ups[3] = {
+      {"skip_conv3", BUF(h, "enc5"), h->w_sk3, h->b_sk3, d.c3, dt, L / 4, x, "xd3"},
+      {"skip_conv2", BUF(h, "enc3"), h->w_sk2, h->b_sk2, d.c2, d.c3, L / 2, BUF(h, "dec3"), "xd2"},
+      {"skip_conv1", BUF(h, "enc1"), h->w_sk1, h->b_sk1, d.c1, d.c2, L, BUF(h, "dec2"), "xd1"}};
+  const ConvBlockW* decs[3] = {&h->dec3, &h->dec2, &h->dec1};
+  const char* dn[3] = {"dec3", "dec2", "dec1"};
+  for (int i = 0; i < 3; ++i) {
+    const UP& u = ups[i];
+    GemmParams p = gp_base(c, u.L, u.cout);   // upsample(x) + skip_conv(h)  (model.py:169-175)
+    p.seg[0] = GemmSeg{u.skip_in, u.w, u.cin, 3, 0};
+    p.bias0 = u.b;
+    p.res2 = u.low;
+    p.res2_half = 1;
+    p.out = BUF(h, u.out);
+    run_gemm(c, "skip_conv_up", p);
+    tap(c, std::string(u.name) + "+up", u.out, u.L, u.cout);
+    conv_block(c, dn[i], *decs[i], BUF(h, u.out), u.L, BUF(h, dn[i]), i == 2, nullptr);
+  }
+}
+
+int check_shapes(dhw_handle* h, int B, int L, int Lt) {
+  const dhw_dims& d = h->dims;
+  if (B < 1 || B > d.max_B || L < 8 || L > d.max_L || L % 8 || Lt < 1 || Lt > d.max_Lt)
+    return fail(h, DHW_ERR_ARG, "shape out of range: B=%d (max %d) L=%d (max %d, multiple of 8) Lt=%d (max %d)", B, d.max_B, L, d.max_L, Lt, d.max_Lt);
+  return 0;
+}
+
+int ensure_film_T(dhw_handle* h, int T) {
+  if (T <= h->film_T_cap) return 0;
+  int rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_sigma_T, (size_t)T * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_sig32_T, (size_t)T * SIG * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_film_T, (size_t)T * 2 * h->film_tot * 4))) return rc;
+  h->film_T_cap = T;
+  h->film_T_ready = 0;
+  return 0;
+}
+
+void schedule_host(int T, std::vector<float>& beta, std::vector<float>& alpha) {
+  // utils/nn.py:19-39 in fp32: torch.linspace evaluates start + step*i below the midpoint and
+  // end - step*(n-1-i) above it; then exp, + 0.02, cumprod(1 - beta) (inference.py:81).
+  beta.resize(T);
+  alpha.resize(T);
+  const float lo = (float)std::log(1e-5), hi = (float)std::log(0.4);
+  const float step = T > 1 ? (hi - lo) / (float)(T - 1) : 0.f;
+  const int half = T / 2;
+  float a = 1.f;
+  for (int i = 0; i < T; ++i) {
+    const float x = i < half ? lo + step * (float)i : hi - step * (float)(T - 1 - i);
+    beta[i] = 0.02f + expf(x);
+    a = a * (1.0f - beta[i]);
+    alpha[i] = a;
+  }
+}
+
+}  // namespace
+
+// ================================================================= C-ABI
+extern "C" {
+
+const char* dhw_version(void) { return "dhw-hip 0.1 (gfx950)"; }
+
+const char* dhw_last_error(dhw_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int dhw_schedule(int T, float* beta_out, float* alpha_bar_out) {
+  if (T < 1 || !beta_out || !alpha_bar_out) return fail(nullptr, DHW_ERR_ARG, "dhw_schedule: bad args");
+  std::vector<float> b, a;
+  schedule_host(T, b, a);
+  std::memcpy(beta_out, b.data(), T * 4);
+  std::memcpy(alpha_bar_out, a.data(), T * 4);
+  return 0;
+}
+
+int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
+  if (!out || !dims) return fail(nullptr, DHW_ERR_ARG, "dhw_create: null argument");
+  *out = nullptr;
+  const dhw_dims& d = *dims;
+  if (d.c1 != 128 || d.c3 != 256) return fail(nullptr, DHW_ERR_ARG, "c1 must be 128 and c3 256 (reference conditioning.py:9-10, model.py:103)");
+  if (d.c2 != 192) return fail(nullptr, DHW_ERR_ARG, "c2 must be 192: the attention kernels are built for head dims 64 (c2/3, c3/4, 2*c2/6) and 48 (2*c2/8)");
+  if (d.num_layers < 0 || d.num_layers > 16 || d.max_B < 1 || d.max_L < 8 || d.max_L % 8 || d.max_Lt < 1 || d.S < 1 || (d.S * 1280) % STYLE_CH)
+    return fail(nullptr, DHW_ERR_ARG, "dhw_create: bad dims");
+  if (d.precision != DHW_PREC_BF16 && d.precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "bad precision");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, DHW_ERR_HIP, "no HIP device available");
+  if (device < 0 || device >= ndev) return fail(nullptr, DHW_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+  dhw_handle* h = new dhw_handle();
+  h->dims = d;
+  h->device = device;
+  h->prec = d.precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
+  h->es = h->prec == PREC_F32 ? 4 : 2;
+  h->spec = build_spec(d.num_layers, d.c1, d.c2, d.c3);
+  for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
+  h->host_w.resize(h->spec.size());
+  h->loaded.assign(h->spec.size(), 0);
+  build_film_layout(h);
+  if (hipSetDevice(device) != hipSuccess) { delete h; return fail(nullptr, DHW_ERR_HIP, "hipSetDevice failed"); }
+  int rc = alloc_workspace(h);
+  if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc) { g_err = h->err; dhw_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+void dhw_destroy(dhw_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+}
+
+int dhw_num_keys(dhw_handle* h) { return h ? (int)h->spec.size() : DHW_ERR_ARG; }
+
+int dhw_key_info(dhw_handle* h, int i, const char** key, int64_t shape[3], int* ndim) {
+  if (!h || i < 0 || i >= (int)h->spec.size()) return fail(h, DHW_ERR_ARG, "dhw_key_info: index out of range");
+  const KeySpec& k = h->spec[i];
+  if (key) *key = k.key.c_str();
+  if (ndim) *ndim = (int)k.shape.size();
+  if (shape) for (size_t j = 0; j < 3; ++j) shape[j] = j < k.shape.size() ? k.shape[j] : 1;
+  return 0;
+}
+
+int dhw_load(dhw_handle* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+  if (!h || !key || !host_ptr || !shape) return fail(h, DHW_ERR_ARG, "dhw_load: null argument");
+  auto it = h->key_index.find(key);
+  if (it == h->key_index.end()) return fail(h, DHW_ERR_KEY, "unexpected key in state_dict: %s", key);
+  const KeySpec& k = h->spec[it->second];
+  bool ok = ndim == (int)k.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == k.shape[i];
+  if (!ok) return fail(h, DHW_ERR_KEY, "size mismatch for %s", key);
+  size_t n = 1;
+  for (int64_t s : k.shape) n *= (size_t)s;
+  std::vector<float>& dst = h->host_w[it->second];
+  dst.resize(n);
+  switch (dtype) {
+    case DHW_F32: std::memcpy(dst.data(), host_ptr, n * 4); break;
+    case DHW_BF16: for (size_t i = 0; i < n; ++i) dst[i] = bf2f(((const uint16_t*)host_ptr)[i]); break;
+    case DHW_F16: for (size_t i = 0; i < n; ++i) dst[i] = h2f(((const uint16_t*)host_ptr)[i]); break;
+    case DHW_F64: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double*)host_ptr)[i]; break;
+    default: return fail(h, DHW_ERR_ARG, "dhw_load: unknown dtype %d", dtype);
+  }
+  h->loaded[it->second] = 1;
+  h->packed = false;
+  return 0;
+}
+
+int dhw_finalize(dhw_handle* h) {
+  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+  if (h->packed) return 0;
+  for (size_t i = 0; i < h->spec.size(); ++i)
+    if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in state_dict: %s", h->spec[i].key.c_str());
+  HIPCK(h, hipSetDevice(h->device));
+  HIPCK(h, hipDeviceSynchronize());
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_key.clear(); }
+  const dhw_dims& d = h->dims;
+  const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
+  int rc;
+  // (re-packing leaks the previous packed copies until destroy; weights are loaded once in practice)
+  {  // FiLM: all gamma/beta projections concatenated -> [2*TOT, 32]
+    std::vector<float> w((size_t)2 * h->film_tot * SIG), b((size_t)2 * h->film_tot);
+    for (auto& kv : h->film_off) {
+      const auto& gw = W(h, kv.first + ".gamma_emb.weight");
+      const auto& gb = W(h, kv.first + ".gamma_emb.bias");
+      const auto& bw = W(h, kv.first + ".beta_emb.weight");
+      const auto& bb = W(h, kv.first + ".beta_emb.bias");
+      std::copy(gw.begin(), gw.end(), w.begin() + (size_t)kv.second * SIG);
+      std::copy(gb.begin(), gb.end(), b.begin() + kv.second);
+      std::copy(bw.begin(), bw.end(), w.begin() + (size_t)(h->film_tot + kv.second) * SIG);
+      std::copy(bb.begin(), bb.end(), b.begin() + h->film_tot + kv.second);
+    }
+    if ((rc = upload_f32(h, w, &h->d_film_w))) return rc;
+    if ((rc = upload_f32(h, b, &h->d_film_b))) return rc;
+  }
+#define UPF(dst, key) if ((rc = upload_f32(h, W(h, key), &h->dst))) return rc
+  UPF(sg_w1, "sigma_ffn.1.weight"); UPF(sg_b1, "sigma_ffn.1.bias"); UPF(sg_w2, "sigma_ffn.3.weight"); UPF(sg_b2, "sigma_ffn.3.bias");
+  UPF(in_w, "input_dense.weight"); UPF(in_b, "input_dense.bias");
+  UPF(out_w, "output_dense.weight"); UPF(out_b, "output_dense.bias");
+  UPF(pen_w, "pen_lifts_dense.0.weight"); UPF(pen_b, "pen_lifts_dense.0.bias");
+  UPF(emb, "text_style_model.emb.weight");
+  const std::string t = "text_style_model";
+  UPF(b_sf1, t + ".style_ffn.1.bias"); UPF(b_sf3, t + ".style_ffn.3.bias"); UPF(b_q8, t + ".mha.wq.bias");
+  UPF(b_d8, t + ".mha.dense.bias"); UPF(b_tf1, t + ".text_ffn.1.bias"); UPF(b_tf3, t + ".text_ffn.3.bias");
+  UPF(b_attd, "att_dense.bias"); UPF(b_sk1, "skip_conv1.bias"); UPF(b_sk2, "skip_conv2.bias"); UPF(b_sk3, "skip_conv3.bias");
+#undef UPF
+  if ((rc = upload_f32(h, vcat({&W(h, t + ".mha.wk.bias"), &W(h, t + ".mha.wv.bias")}), &h->b_kv8))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".style_ffn.1.weight"), 4 * c2, STYLE_CH, &h->w_sf1))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".style_ffn.3.weight"), dt, 4 * c2, &h->w_sf3))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".mha.wq.weight"), dt, dt, &h->w_q8))) return rc;
+  if ((rc = upload_packed(h, vcat({&W(h, t + ".mha.wk.weight"), &W(h, t + ".mha.wv.weight")}), 2 * dt, dt, &h->w_kv8))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".mha.dense.weight"), dt, dt, &h->w_d8))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".text_ffn.1.weight"), 2 * dt, dt, &h->w_tf1))) return rc;
+  if ((rc = upload_packed(h, W(h, t + ".text_ffn.3.weight"), dt, 2 * dt, &h->w_tf3))) return rc;
+  if ((rc = upload_packed(h, W(h, "att_dense.weight"), dt, 2 * c1, &h->w_attd))) return rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv1.weight"), c2, c1), c2, 3 * c1, &h->w_sk1))) return rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv2.weight"), c3, c2), c3, 3 * c2, &h->w_sk2))) return rc;
+  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv3.weight"), dt, c3), dt, 3 * c3, &h->w_sk3))) return rc;
+  h->f_ts1 = h->film_off.at(t + ".affine1");
+  h->f_ts2 = h->film_off.at(t + ".affine2");
+  h->f_ts3 = h->film_off.at(t + ".affine3");
+  h->f_ts4 = h->film_off.at(t + ".affine4");
+  if ((rc = pack_convblock(h, "enc1", c1, c1, h->enc1))) return rc;
+  if ((rc = pack_convblock(h, "enc2", c1, c2, h->enc2))) return rc;
+  if ((rc = pack_convblock(h, "enc4", c2, c3, h->enc4))) return rc;
+  if ((rc = pack_convblock(h, "dec3", dt, c3, h->dec3))) return rc;
+  if ((rc = pack_convblock(h, "dec2", c3, c2, h->dec2))) return rc;
+  if ((rc = pack_convblock(h, "dec1", c2, c1, h->dec1))) return rc;
+  h->el.assign(2 + d.num_layers, EncLayerW{});
+  if ((rc = pack_enclayer(h, "enc3", c2, 3, 4.0f, d.max_L / 2, h->el[0]))) return rc;   // model.py:88
+  if ((rc = pack_enclayer(h, "enc5", c3, 4, 2.0f, d.max_L / 4, h->el[1]))) return rc;   // model.py:90
+  for (int i = 0; i < d.num_layers; ++i)
+    if ((rc = pack_enclayer(h, "att_layers." + std::to_string(i), dt, 6, 1.0f, d.max_L / 8, h->el[2 + i]))) return rc;   // model.py:104-109
+  HIPCK(h, hipDeviceSynchronize());
+  h->packed = true;
+  h->film_T_ready = 0;
+  return 0;
+}
+
+static int launch_heads_for(Ctx& c, HeadsParams hp) {
+  dhw_handle* h = c.h;
+  hp.x = (const float*)BUF(h, "dec1");
+  hp.rows = (long)c.B * c.L;
+  hp.C = h->dims.c1;
+  hp.w_out = h->out_w; hp.b_out = h->out_b; hp.w_pen = h->pen_w; hp.b_pen = h->pen_b;
+  hp.L = c.L;
+  RUN_SMALL(c, "heads_step", launch_heads(hp, c.st));
+  return c.err;
+}
+
+int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const float* sigma, const float* style,
+                int B, int L, int Lt, float* eps_out, float* pen_out, void* hip_stream) {
+  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+  if (!strokes || !text || !sigma || !style || !eps_out || !pen_out) return fail(h, DHW_ERR_ARG, "dhw_forward: null pointer");
+  int rc = check_shapes(h, B, L, Lt);
+  if (rc) return rc;
+  if ((rc = dhw_finalize(h))) return rc;
+  HIPCK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
+  h->taps.clear();
+  RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(sigma, B, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32, st));
+  RUN_SMALL(c, "film_table", launch_film(h->d_sig32, B, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film, st));
+  h->taps["sigma_ffn"] = Tap{h->d_sig32, 1, SIG, true};
+  text_style_static(c, text, style);
+  text_style_dynamic(c);
+  stroke_path(c, strokes, text);
+  HeadsParams hp{};
+  hp.eps = eps_out;
+  hp.pen = pen_out;
+  launch_heads_for(c, hp);
+  h->last_B = B; h->last_L = L; h->last_Lt = Lt;
+  return c.err;
+}
+
+static int sample_enqueue(dhw_handle* h, const int64_t* text, const float* style, int B, int L, int Lt, int T, int mode,
+                          const float* noise, float* out, hipStream_t st, const std::vector<float>& beta,
+                          const std::vector<float>& alpha) {
+  const long rows = (long)B * L;
+  Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
+  h->taps.clear();
+  // x_T
+  if (noise) {
+    hipError_t e = hipMemcpyAsync(h->d_xt, noise, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy x_T: %s", hipGetErrorString(e));
+  } else {
+    RUN_SMALL(c, "randn_init", launch_randn_init(h->d_xt, rows, L, h->d_seed, st));
+  }
+  text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
+  for (int step = 0, i = T - 1; i >= 0; --i, ++step) {
+    c.film = h->d_film_T + (size_t)i * 2 * h->film_tot;
+    text_style_dynamic(c);
+    stroke_path(c, h->d_xt, text);
+    HeadsParams hp{};
+    hp.eps = nullptr;
+    hp.pen = nullptr;
+    hp.xt = h->d_xt;
+    hp.z = noise ? noise + (size_t)(1 + step) * rows * 2 : nullptr;
+    hp.mode = mode;
+    hp.seed_ptr = h->d_seed;
+    hp.iter = step;
+    const float a = alpha[i], b = beta[i];
+    const float a_next = i > 1 ? alpha[i - 1] : 1.0f;   // inference.py:87
+    hp.k0 = sqrtf(1.0f - a);
+    if (mode == 0) {
+      hp.k1 = sqrtf(1.0f - b);
+      hp.k2 = sqrtf(1.0f - a_next);
+      hp.add_noise = 1;
+    } else {
+      hp.k1 = 1.0f / sqrtf(1.0f - b);
+      hp.k2 = sqrtf(b);
+      hp.k3 = b;
+      hp.add_noise = i != 0;   // inference.py:92
+    }
+    if (i == 0) hp.out3 = out;
+    launch_heads_for(c, hp);
+    if (c.err) return c.err;
+  }
+  return c.err;
+}
+
+int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, int L, int Lt, int T, int mode,
+               const float* noise, uint64_t seed, int64_t first_sample, float* out, void* hip_stream) {
+  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+  if (!text || !style || !out) return fail(h, DHW_ERR_ARG, "dhw_sample: null pointer");
+  if (T < 1 || (mode != 0 && mode != 1)) return fail(h, DHW_ERR_ARG, "dhw_sample: bad T/mode");
+  int rc = check_shapes(h, B, L, Lt);
+  if (rc) return rc;
+  if ((rc = dhw_finalize(h))) return rc;
+  HIPCK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  if ((rc = ensure_film_T(h, T))) return rc;
+  std::vector<float> beta, alpha, sig(T);
+  schedule_host(T, beta, alpha);
+  for (int i = 0; i < T; ++i) sig[i] = sqrtf(alpha[i]);   // inference.py:89
+  if (h->film_T_ready != T) {
+    // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]
+    HIPCK(h, hipMemcpy(h->d_sigma_T, sig.data(), T * 4, hipMemcpyHostToDevice));
+    Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
+    RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(h->d_sigma_T, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32_T, st));
+    RUN_SMALL(c, "film_table", launch_film(h->d_sig32_T, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film_T, st));
+    if (c.err) return c.err;
+    h->film_T_ready = T;
+  }
+  {
+    hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, st);
+    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "set_seed: %s", hipGetErrorString(e));
+  }
+
+  const bool graph = h->use_graph && !h->prof;
+  if (!graph) {
+    rc = sample_enqueue(h, text, style, B, L, Lt, T, mode, noise, out, st, beta, alpha);
+  } else {
+    std::vector<uint64_t> key = {(uint64_t)text, (uint64_t)style, (uint64_t)noise, (uint64_t)out, (uint64_t)B,
+                                 (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode};
+    if (!h->graph_exec || key != h->graph_key) {
+      if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+      hipStream_t cs;
+      HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      HIPCK(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      rc = sample_enqueue(h, text, style, B, L, Lt, T, mode, noise, out, cs, beta, alpha);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(cs, &g);
+      if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+      if (rc == 0) {
+        e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph instantiate failed: %s", hipGetErrorString(e));
+      }
+      if (g) hipGraphDestroy(g);
+      hipStreamDestroy(cs);
+      if (rc) { h->graph_exec = nullptr; return rc; }
+      h->graph_key = key;
+    }
+    HIPCK(h, hipGraphLaunch(h->graph_exec, st));
+  }
+  h->last_B = B; h->last_L = L; h->last_Lt = Lt;
+  return rc;
+}
+
+int dhw_work(dhw_handle* h, int L, int Lt, double* flops_out, double* bytes_out) {
+  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+  const dhw_dims& d = h->dims;
+  const double c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2, S5 = d.S * 5;
+  auto cb = [](double L_, double ci, double co) { return 2 * L_ * (3 * ci * co + 1.5 * ci * co + 1.5 * co * co + co * co); };
+  auto el = [&](double Lk, double dm, double heads) {
+    double f = 2 * Lt * dt * dm + 2 * Lt * dm * dm * 2;            // text_dense, k1, v1
+    f += 2 * Lk * dm * dm * 2 + 2 * Lk * dm * dm * 4;              // q1, dense1, qkv2, dense2
+    f += 2 * Lk * dm * 2 * dm * 2;                                 // ffn
+    f += 4 * Lk * Lt * dm + 4 * Lk * Lk * dm;                      // SDPA cross + self
+    (void)heads;
+    return f;
+  };
+  double f = 0;
+  f += 2 * S5 * (STYLE_CH * 4 * c2 + 4 * c2 * dt) + 2 * Lt * dt * dt * 2 + 2 * S5 * dt * dt * 2 + 4 * Lt * S5 * dt + 2 * Lt * dt * 2 * dt * 2;
+  f += 2 * L * 2 * c1;
+  f += cb(L, c1, c1) + cb(L / 2, c1, c2) + cb(L / 4, c2, c3) + cb(L / 4, dt, c3) + cb(L / 2, c3, c2) + cb(L, c2, c1);
+  f += el(L / 2, c2, 3) + el(L / 4, c3, 4) + d.num_layers * el(L / 8, dt, 6);
+  f += 2 * (L / 8) * c3 * dt;
+  f += 2 * 3 * ((L / 4) * c3 * dt + (L / 2) * c2 * c3 + L * c1 * c2);
+  f += 2 * L * c1 * 3;
+  // block-boundary activation bytes: every top-level block reads its inputs and writes its outputs once
+  const double es = (double)h->es;
+  double by = 0;
+  by += L * 2 * 4 + L * 3 * 4;                                                  // strokes in, eps+pen out (fp32)
+  by += es * (L * c1 * 2 + (L / 2) * (c1 + c2) + (L / 4) * (c2 + c3) + (L / 4) * (dt + c3) + (L / 2) * (c3 + c2) + L * (c2 + c1));   // ConvBlocks
+  by += es * 2 * ((L / 2) * c2 + (L / 4) * c3 + d.num_layers * (L / 8) * dt);   // EncoderLayers
+  by += es * ((L / 8) * (c3 + dt));                                             // att_dense
+  by += es * ((L / 4) * (c3 + dt + dt) + (L / 2) * (c2 + c3 + c3) + L * (c1 + c2 + c2));   // skip convs + upsample add
+  by += es * (S5 * STYLE_CH + Lt * dt * (2 + 2 * (2 + d.num_layers)));          // text/style encoder + per-layer text reads
+  if (flops_out) *flops_out = f;
+  if (bytes_out) *bytes_out = by;
+  return 0;
+}
+
+// ---------------------------------------------------------------- debug / measurement hooks
+int64_t dhw_debug_read(dhw_handle* h, const char* name, float* host_dst, int64_t max_floats, int64_t shape_out[3]) {
+  if (!h || !name || !host_dst) return fail(h, DHW_ERR_ARG, "dhw_debug_read: null argument");
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) return fail(h, DHW_ERR_ARG, "no activation named %s", name);
+  const Tap& t = it->second;
+  const int64_t n = (int64_t)h->last_B * t.rows * t.cols;
+  if (n > max_floats) return fail(h, DHW_ERR_ARG, "buffer too small for %s", name);
+  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(h, DHW_ERR_HIP, "sync failed: %s", hipGetErrorString(hipGetLastError()));
+  if (shape_out) { shape_out[0] = h->last_B; shape_out[1] = t.rows; shape_out[2] = t.cols; }
+  if (t.f32 || h->prec == PREC_F32) {
+    if (hipMemcpy(host_dst, t.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+  } else {
+    std::vector<uint16_t> tmp(n);
+    if (hipMemcpy(tmp.data(), t.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+    for (int64_t i = 0; i < n; ++i) host_dst[i] = bf2f(tmp[i]);
+  }
+  return n;
+}
+
+int dhw_profile_enable(dhw_handle* h, int on) {
+  if (!h) return DHW_ERR_ARG;
+  h->prof = on != 0;
+  return 0;
+}
+int dhw_profile_reset(dhw_handle* h) {
+  if (!h) return DHW_ERR_ARG;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  h->prof_recs.clear();
+  h->prof_agg.clear();
+  return 0;
+}
+int dhw_profile_count(dhw_handle* h) {
+  if (!h) return DHW_ERR_ARG;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  h->prof_agg.assign(h->prof_labels.size(), ProfAgg{});
+  for (size_t i = 0; i < h->prof_labels.size(); ++i) h->prof_agg[i].label = h->prof_labels[i];
+  for (auto& r : h->prof_recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    ProfAgg& a = h->prof_agg[r.label];
+    a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.n += 1;
+  }
+  return (int)h->prof_agg.size();
+}
+int dhw_profile_get(dhw_handle* h, int i, const char** label, double* total_ms, int64_t* launches, double* flops_sum,
+                    double* bytes_sum) {
+  if (!h || i < 0 || i >= (int)h->prof_agg.size()) return DHW_ERR_ARG;
+  const ProfAgg& a = h->prof_agg[i];
+  if (label) *label = a.label.c_str();
+  if (total_ms) *total_ms = a.ms;
+  if (launches) *launches = a.n;
+  if (flops_sum) *flops_sum = a.flops;
+  if (bytes_sum) *bytes_sum = a.bytes;
+  return 0;
+}
+int dhw_set_graph(dhw_handle* h, int on) {
+  if (!h) return DHW_ERR_ARG;
+  h->use_graph = on != 0;
+  return 0;
+}
+
+}  // extern "C"

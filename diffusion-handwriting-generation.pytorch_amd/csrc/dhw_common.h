@@ -1,0 +1,87 @@
+// dhw_common.h — shared device helpers for the gfx950 kernels.
+//
+// MFMA conventions used everywhere (cdna_hip_programming.md §3):
+//   * one "k-chunk" = 32 contraction elements; a fragment holds, per lane,
+//     the 8 consecutive k-elements  k = 8*(lane>>4) + j  of row/col (lane&15).
+//   * bf16: one v_mfma_f32_16x16x32_bf16 per k-chunk.
+//   * f32 : eight v_mfma_f32_16x16x4_f32 per k-chunk (MFMA i consumes element
+//     j = i of both fragments: the 4 lane groups then supply k = 8g+i — any
+//     k-permutation is fine as long as A and B agree).  Exact f32.
+//   * accumulator tile 16x16: acc[r] = C[row = 4*(lane>>4) + r][col = lane&15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DHW_DEV __device__ __forceinline__
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { f32x4 lo, hi; };
+
+// acc += A(16 x 32) * B(32 x 16); a = A-operand fragment (rows), b = B-operand fragment (cols)
+DHW_DEV void mma32(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+DHW_DEV void mma32(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[0], b.lo[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[1], b.lo[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[2], b.lo[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[3], b.lo[3], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[0], b.hi[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[1], b.hi[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[2], b.hi[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
+}
+
+// load a fragment (8 consecutive elements) from a 16-byte aligned address
+DHW_DEV Frag<bf16_t> frag_load(const bf16_t* p) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(p);
+  return f;
+}
+DHW_DEV Frag<float> frag_load(const float* p) {
+  Frag<float> f;
+  f.lo = *reinterpret_cast<const f32x4*>(p);
+  f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+  return f;
+}
+template <typename T> DHW_DEV Frag<T> frag_zero();
+template <> DHW_DEV Frag<bf16_t> frag_zero<bf16_t>() {
+  Frag<bf16_t> f;
+  for (int i = 0; i < 8; ++i) f.v[i] = (bf16_t)0.0f;
+  return f;
+}
+template <> DHW_DEV Frag<float> frag_zero<float>() {
+  Frag<float> f;
+  f.lo = (f32x4){0, 0, 0, 0};
+  f.hi = (f32x4){0, 0, 0, 0};
+  return f;
+}
+// fragment from two groups of 4 fp32 values (element j<4 from a, j>=4 from b)
+DHW_DEV void frag_from_f32(Frag<bf16_t>& f, const f32x4& a, const f32x4& b) {
+  for (int i = 0; i < 4; ++i) { f.v[i] = (bf16_t)a[i]; f.v[4 + i] = (bf16_t)b[i]; }
+}
+DHW_DEV void frag_from_f32(Frag<float>& f, const f32x4& a, const f32x4& b) { f.lo = a; f.hi = b; }
+
+// 4 consecutive elements <-> f32x4
+DHW_DEV f32x4 load4(const bf16_t* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+DHW_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+DHW_DEV void store4(bf16_t* p, const f32x4& v) {
+  bf16x4 o;
+  for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+DHW_DEV void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+DHW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+DHW_DEV float to_f(bf16_t x) { return (float)x; }
+DHW_DEV float to_f(float x) { return x; }
+template <typename T> DHW_DEV T from_f(float x) { return (T)x; }

@@ -1,0 +1,104 @@
+// dhw_kernels.h — host-side launch interface of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { PREC_BF16 = 0, PREC_F32 = 1 };
+
+// ---------------------------------------------------------------- fused GEMM
+// out[b, m, n] = epilogue( sum_seg sum_tap sum_c  act_seg[b, m + tap - halo, c] * W_seg[n][tap*C + c] )
+// All activations are C-last [B, L, C] of the handle's element type.
+struct GemmSeg {
+  const void* A;   // activations [B*L (+slack), C]
+  const void* W;   // packed weights: [N/16][taps*C/32][64 lanes][8] of the element type
+  int C;           // input channels (multiple of 32)
+  int taps;        // 1 (Linear) or 3 (Conv1d k=3, zero 'same' padding inside each sample)
+  int silu;        // apply SiLU to the activations while staging
+};
+
+struct GemmParams {
+  GemmSeg seg[2];
+  int nseg;
+  int B, L;              // samples, rows per sample
+  int N;                 // output channels (multiple of 16)
+  int n_store;           // columns [0,n_store) -> out (row stride n_store); [n_store,N) -> vt (transposed)
+  const float* bias0;    // [N] added after segment 0
+  const float* bias1;    // [N] added after segment 1 (nseg == 2) or null
+  const float* posb;     // [>=L][posb_cols] position bias (PE·W), added for n < posb_cols; or null
+  int posb_cols;
+  const float* gam;      // FiLM gamma/beta for this layer: gam[b*film_bs + n]
+  const float* bet;
+  long film_bs;          // batch stride of the FiLM table (0 inside the sampling loop)
+  int film_mode;         // 0 none; 1 after (LN); 2 between segment 0 and 1 (ConvBlock: FiLM3(fc)+conv_skip)
+  const void* res1;      // [B*L, N] added before LN, or null
+  const void* res2;      // added after FiLM: [B*L, N], or [B*L/2, N] when res2_half (nearest x2 upsample)
+  int res2_half;
+  int ln;                // LayerNorm over the N channels (eps 1e-6, no affine); needs BN == N
+  int silu_out;
+  void* out;             // [B*L, n_store] element type, or fp32 when out_f32
+  int out_f32;
+  void* pool;            // optional second output: AvgPool1d(2) over rows, [B*L/2, N]
+  void* vt;              // [B][N-n_store][vt_lpad] element type (keys contiguous)
+  int vt_lpad;
+};
+
+// returns hipError; chooses the tile from (prec, L, N, ln)
+hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st);
+// tile actually chosen (for tests / work accounting)
+void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN);
+
+// ---------------------------------------------------------------- attention
+struct AttnParams {
+  const void* Q; int ldq;      // Q[(b*Lq + q)*ldq + h*D + d]
+  const void* K; int ldk; int koff;  // K[(b*Lk + k)*ldk + koff + h*D + d]
+  const void* Vt; int lpad;    // Vt[((b*H + h)*D + d)*lpad + k]
+  const int64_t* text; int ldt; // key padding mask: key k masked (score += -1e9) iff text[b*ldt + k] == 0; null = none
+  void* out; int ldo;          // out[(b*Lq + q)*ldo + h*D + d]
+  int B, H, D, Lq, Lk;
+};
+hipError_t launch_attn(int prec, const AttnParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------- small kernels
+// sigma_ffn: sig32[n,32] = W2 SiLU(W1 SiLU(sigma) + b1) + b2        (model.py:83,134)
+hipError_t launch_sigma_ffn(const float* sigma, int n, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* sig32, hipStream_t st);
+// FiLM table: film[n, cols] = sig32[n,32] · Wcat[cols,32]^T + bcat   (conditioning.py:16-18, all layers at once)
+hipError_t launch_film(const float* sig32, int n, const float* wcat, const float* bcat, int cols,
+                       float* film, hipStream_t st);
+// t_n = LN(emb[text])  (text_style.py:96-97), element type out
+hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int vocab,
+                           void* out, hipStream_t st);
+// out[b, r, c] = in[b, r, c] * gam[b*bs + c] + bet[b*bs + c]
+hipError_t launch_film_apply(int prec, const void* in, int B, int rows, int dim, const float* gam,
+                             const float* bet, long bs, void* out, hipStream_t st);
+// fp32 -> element type
+hipError_t launch_cast(int prec, const float* in, long n, void* out, hipStream_t st);
+// x0[b,l,:] = W[:,0]*s0 + W[:,1]*s1 + bias   (model.py:139)
+hipError_t launch_input_dense(int prec, const float* strokes, long rows, const float* w, const float* b,
+                              int C, void* out, hipStream_t st);
+
+// heads (+ optional fused scheduler step).  x: fp32 [rows, C] (dec1 output).
+struct HeadsParams {
+  const float* x; long rows; int C;
+  const float* w_out; const float* b_out;   // [2,C],[2]
+  const float* w_pen; const float* b_pen;   // [1,C],[1]
+  float* eps; float* pen;                   // [rows,2], [rows]  (pen may be null)
+  // fused scheduler step (null xt = none): xt <- step(xt, eps, z), reference operation order
+  float* xt;               // [rows,2] fp32 sampler state, updated in place
+  const float* z;          // [rows,2] external noise or null (=> Philox)
+  int mode;                // 0 new (utils/nn.py:110-112), 1 standard (utils/nn.py:84-87)
+  int add_noise;           // standard mode: bool(i) (inference.py:92); new mode: always 1
+  float k0;                // sqrt(1 - abar_i)
+  float k1;                // new: sqrt(1 - beta_i);  standard: 1 / sqrt(1 - beta_i)
+  float k2;                // new: sqrt(1 - abar_next);  standard: sqrt(beta_i)
+  float k3;                // standard: beta_i
+  const uint64_t* seed_ptr; int L; int iter;   // Philox: device [seed, first_sample]; counter = (sample, pos, iter)
+  float* out3;             // optional [rows,3] final cat(x, pen)
+};
+hipError_t launch_heads(const HeadsParams& p, hipStream_t st);
+// x_T ~ N(0,1) from Philox, same keying as the per-step draws (iter = -1)
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, hipStream_t st);
+// seed_ptr[0] = seed, seed_ptr[1] = first_sample (by-value kernel arguments: no host buffer lifetime)
+hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st);
+// one-time per-process kernel attribute setup (dynamic LDS > 64 KiB)
+hipError_t gemm_init();

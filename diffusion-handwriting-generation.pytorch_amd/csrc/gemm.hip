@@ -1,0 +1,341 @@
+// gemm.hip — the fused "activation-stationary" MFMA GEMM that carries every
+// Linear / Conv1d(k=3) of the denoiser (reference cnn.py:64-87, model.py:37-58,
+// text_style.py:91-104, attention.py:78-85), with the surrounding elementwise
+// work fused into its prologue/epilogue:
+//
+//   prologue : SiLU on the activations while they are staged into LDS;
+//              k=3 taps read three row-shifted views of ONE staged tile (+halo)
+//   mainloop : weights are pre-packed in MFMA-fragment order, so each wave
+//              streams its own 1-KiB-contiguous weight fragments straight from
+//              L2 into VGPRs (no LDS, no barrier in the loop); activations are
+//              staged once per workgroup and read as ds_read_b128 fragments
+//   epilogue : bias, PE·W position bias, residual, LayerNorm (cross-wave),
+//              sigma-FiLM, residual / nearest-upsampled residual, SiLU,
+//              AvgPool1d(2) side output, transposed V side output.
+//
+// Orientation: the MFMA "A" operand is the WEIGHT fragment (rows = output
+// channels) and the "B" operand the ACTIVATION fragment (cols = stroke rows),
+// so each lane ends up with 4 consecutive output channels of one stroke row:
+// C-last stores are 8/16-byte vectors and LayerNorm needs 2 shuffles.
+//
+// A workgroup = 4 waves computes BM rows (of one sample) x BN channels; waves
+// are arranged WM x WN, each owning (BM/WM) x (BN/WN).
+#include "dhw_common.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int MT = BM / WM / 16;   // activation (column) tiles per wave
+  constexpr int NT = BN / WN / 16;   // channel (row) tiles per wave
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int tiles = (p.L + BM - 1) / BM;
+  const int b = blockIdx.x / tiles;
+  const int m0 = (blockIdx.x % tiles) * BM;
+  const int nb0 = blockIdx.y * BN;
+
+  // ---- LDS carve: one activation tile per segment, then LN scratch
+  int lds_off[2], lds_stride[2];
+  int off = 0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    lds_off[s] = off;
+    lds_stride[s] = 0;
+    if (s < p.nseg) {
+      const int rows = BM + (p.seg[s].taps == 3 ? 2 : 0);
+      lds_stride[s] = p.seg[s].C * ES + 16;
+      off += rows * lds_stride[s];
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem + off);   // [2][WN][BM]
+
+  // ---- stage activations (zero outside the sample: 'same' padding and row tail)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (s >= p.nseg) break;
+    const GemmSeg& sg = p.seg[s];
+    const int halo = sg.taps == 3 ? 1 : 0;
+    const int rows = BM + 2 * halo;
+    const int cpr = sg.C * ES / 16;              // 16-byte chunks per row
+    const int total = rows * cpr;
+    const char* src = reinterpret_cast<const char*>(sg.A);
+    for (int id = tid; id < total; id += 256) {
+      const int r = id / cpr, cc = id - r * cpr;
+      const int lrow = m0 - halo + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (lrow >= 0 && lrow < p.L) {
+        v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * sg.C) * ES + (size_t)cc * 16);
+        if (sg.silu) {
+          T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+          for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_f(to_f(e[i])));
+        }
+      }
+      *reinterpret_cast<uint4*>(smem + lds_off[s] + r * lds_stride[s] + cc * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+  const int ntile0 = (nb0 + wn * (BN / WN)) / 16;   // first global channel tile of this wave
+  const int row0 = wm * (BM / WM);                  // first tile-local row of this wave
+
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (s >= p.nseg) break;
+    const GemmSeg& sg = p.seg[s];
+    const int KC = sg.C / 32;
+    const int KT = KC * sg.taps;                    // k-chunks of this segment
+    const T* wbase = reinterpret_cast<const T*>(sg.W) + ((size_t)ntile0 * KT * 64 + lane) * 8;
+    const char* abase = smem + lds_off[s] + (row0 + l15) * lds_stride[s] + g * 8 * ES;
+
+    Frag<T> wcur[NT], wnxt[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wcur[i] = frag_load(wbase + (size_t)i * KT * 512);
+    int tap = 0, kc = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + 1 < KT) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wnxt[i] = frag_load(wbase + ((size_t)i * KT + kt + 1) * 512);
+      }
+      Frag<T> a[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        a[j] = frag_load(reinterpret_cast<const T*>(abase + (j * 16 + tap) * lds_stride[s] + kc * 32 * ES));
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], wcur[i], a[j]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wcur[i] = wnxt[i];
+      if (++kc == KC) { kc = 0; ++tap; }
+    }
+
+    if (s == 0 && p.nseg == 2) {
+      // between the segments: acc = FiLM(acc + bias0) (ConvBlock: affine3(fc(.)), cnn.py:81-82)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = (ntile0 + i) * 16 + 4 * g;
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.bias0 + n);
+        f32x4 ga = (f32x4){1, 1, 1, 1}, be = (f32x4){0, 0, 0, 0};
+        if (p.film_mode == 2) {
+          ga = *reinterpret_cast<const f32x4*>(p.gam + (size_t)b * p.film_bs + n);
+          be = *reinterpret_cast<const f32x4*>(p.bet + (size_t)b * p.film_bs + n);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] + bi) * ga + be;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const float* bias_last = p.nseg == 2 ? p.bias1 : p.bias0;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (ntile0 + i) * 16 + 4 * g;
+    const f32x4 bi = bias_last ? *reinterpret_cast<const f32x4*>(bias_last + n) : (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int lrow = m0 + row0 + j * 16 + l15;
+      f32x4 v = acc[i][j] + bi;
+      if (lrow < p.L) {
+        if (p.posb && n < p.posb_cols) v += *reinterpret_cast<const f32x4*>(p.posb + (size_t)lrow * p.posb_cols + n);
+        if (p.res1) v += load4(reinterpret_cast<const T*>(p.res1) + (size_t)(b * p.L + lrow) * p.N + n);
+      }
+      acc[i][j] = v;
+    }
+  }
+
+  if (p.ln) {
+    // LayerNorm over the N = BN channels of each row (model.py:25: eps 1e-6, no affine); two-pass in fp32.
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (g == 0) red[wn * BM + row0 + j * 16 + l15] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) s += red[w * BM + row0 + j * 16 + l15];
+      mean[j] = s * (1.0f / BN);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (g == 0) red[(WN + wn) * BM + row0 + j * 16 + l15] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) s += red[(WN + w) * BM + row0 + j * 16 + l15];
+      rstd[j] = rsqrtf(s * (1.0f / BN) + 1e-6f);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] - mean[j]) * rstd[j];
+  }
+
+  const int NV = p.N - p.n_store;   // transposed-V columns
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (ntile0 + i) * 16 + 4 * g;
+    f32x4 ga = (f32x4){1, 1, 1, 1}, be = (f32x4){0, 0, 0, 0};
+    if (p.film_mode == 1) {
+      ga = *reinterpret_cast<const f32x4*>(p.gam + (size_t)b * p.film_bs + n);
+      be = *reinterpret_cast<const f32x4*>(p.bet + (size_t)b * p.film_bs + n);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int lrow = m0 + row0 + j * 16 + l15;
+      const bool valid = lrow < p.L;
+      f32x4 v = acc[i][j];
+      if (p.film_mode == 1) v = v * ga + be;
+      if (p.res2 && valid) {
+        const size_t rr = p.res2_half ? (size_t)b * (p.L / 2) + (lrow >> 1) : (size_t)b * p.L + lrow;
+        v += load4(reinterpret_cast<const T*>(p.res2) + rr * p.N + n);
+      }
+      if (p.silu_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (n < p.n_store) {
+        if (valid) {
+          const size_t o = (size_t)(b * p.L + lrow) * p.n_store + n;
+          if (p.out_f32) store4(reinterpret_cast<float*>(p.out) + o, v);
+          else store4(reinterpret_cast<T*>(p.out) + o, v);
+        }
+        if (p.pool) {
+          // AvgPool1d(2) over rows (model.py:93): rows 2i,2i+1 sit in lanes l, l^1
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = 0.5f * (v[r] + __shfl_xor(v[r], 1));
+          if (valid && !(lane & 1))
+            store4(reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + (lrow >> 1)) * p.N + n, o);
+        }
+      } else if (lrow < p.vt_lpad) {
+        // V columns, stored key-contiguous for the attention kernel's PV product; rows past L stay zero
+        T* vt = reinterpret_cast<T*>(p.vt) + ((size_t)b * NV + (n - p.n_store)) * p.vt_lpad + lrow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vt[(size_t)r * p.vt_lpad] = from_f<T>(valid ? v[r] : 0.f);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+hipError_t launch_one(const GemmParams& p, hipStream_t st) {
+  const int tiles = (p.L + BM - 1) / BM;
+  dim3 grid(p.B * tiles, p.N / BN);
+  size_t lds = 0;
+  for (int s = 0; s < p.nseg; ++s)
+    lds += (size_t)(BM + (p.seg[s].taps == 3 ? 2 : 0)) * (p.seg[s].C * sizeof(T) + 16);
+  lds += 2 * WN * BM * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+template <typename T, int BM>
+hipError_t launch_bn(int BN, const GemmParams& p, hipStream_t st) {
+  switch (BN) {
+    case 64: return launch_one<T, BM, 64, 1, 4>(p, st);
+    case 96: return launch_one<T, BM, 96, 2, 2>(p, st);
+    case 128: return launch_one<T, BM, 128, 1, 4>(p, st);
+    case 192: return launch_one<T, BM, 192, 1, 4>(p, st);
+    case 256: return launch_one<T, BM, 256, 1, 4>(p, st);
+    case 384: return launch_one<T, BM, 384, 1, 4>(p, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+hipError_t set_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BM, BN, WM, WN>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <typename T, int BM>
+hipError_t set_attr_bm() {
+  hipError_t e;
+  if ((e = set_attr<T, BM, 64, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 96, 2, 2>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 128, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 192, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 256, 1, 4>()) != hipSuccess) return e;
+  return set_attr<T, BM, 384, 1, 4>();
+}
+
+}  // namespace
+
+hipError_t gemm_init() {
+  hipError_t e;
+  if ((e = set_attr_bm<bf16_t, 64>()) != hipSuccess) return e;
+  if ((e = set_attr_bm<bf16_t, 32>()) != hipSuccess) return e;
+  return set_attr_bm<float, 32>();
+}
+
+void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
+  int bm = 32;
+  if (prec == PREC_BF16 && p.L >= 48) bm = 64;
+  const int cands[6] = {384, 256, 192, 128, 96, 64};
+  int bn = 0;
+  if (p.ln) {
+    bn = p.N;
+  } else {
+    const long tiles = (long)p.B * ((p.L + bm - 1) / bm);
+    // largest BN dividing N that still yields >= 512 workgroups; else the smallest divisor >= 128 (or the only one)
+    for (int c : cands)
+      if (p.N % c == 0 && tiles * (p.N / c) >= 512) { bn = c; break; }
+    if (!bn) {
+      for (int k = 5; k >= 0; --k)
+        if (p.N % cands[k] == 0 && (cands[k] >= 128 || p.N == cands[k])) { bn = cands[k]; break; }
+    }
+    if (!bn)
+      for (int k = 5; k >= 0; --k)
+        if (p.N % cands[k] == 0) { bn = cands[k]; break; }
+  }
+  *BM = bm;
+  *BN = bn;
+}
+
+hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st) {
+  if (p.nseg < 1 || p.nseg > 2 || p.N % 16 || p.n_store % 16 || (p.pool && (p.L & 1))) return hipErrorInvalidValue;
+  for (int s = 0; s < p.nseg; ++s)
+    if (p.seg[s].C % 32 || (p.seg[s].taps != 1 && p.seg[s].taps != 3)) return hipErrorInvalidValue;
+  int bm, bn;
+  gemm_tile_for(prec, p, &bm, &bn);
+  if (!bn) return hipErrorInvalidValue;
+  if (prec == PREC_BF16) {
+    return bm == 64 ? launch_bn<bf16_t, 64>(bn, p, st) : launch_bn<bf16_t, 32>(bn, p, st);
+  }
+  return launch_bn<float, 32>(bn, p, st);
+}

@@ -1,0 +1,251 @@
+// misc.hip — the small kernels around the GEMM/attention core: sigma MLP and the
+// all-layer FiLM table, token embedding + LayerNorm, FiLM apply, input/output
+// heads, and the fused scheduler step with counter-based N(0,1) noise.
+#include "dhw_common.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+// ---- sigma_ffn (model.py:83,134; utils/nn.py:165-175): one workgroup per sigma value
+__global__ __launch_bounds__(256) void sigma_ffn_kernel(const float* sigma, const float* w1, const float* b1,
+                                                         const float* w2, const float* b2, float* sig32) {
+  __shared__ float hid[2048];
+  __shared__ float part[8][32];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float s = silu_f(sigma[n]);
+  for (int j = tid; j < 2048; j += 256) hid[j] = silu_f(w1[j] * s + b1[j]);
+  __syncthreads();
+  // 32 outputs x 8 partial sums over 256-wide slices of the hidden vector
+  const int o = tid & 31, sl = tid >> 5;
+  float acc = 0.f;
+  const float* w = w2 + (size_t)o * 2048 + sl * 256;
+  for (int j = 0; j < 256; ++j) acc += w[j] * hid[sl * 256 + j];
+  part[sl][o] = acc;
+  __syncthreads();
+  if (tid < 32) {
+    float t = b2[tid];
+    for (int k = 0; k < 8; ++k) t += part[k][tid];
+    sig32[n * 32 + tid] = t;
+  }
+}
+
+// ---- FiLM table: all gamma/beta Linears(32 -> C) of the model at once (conditioning.py:16-18)
+__global__ __launch_bounds__(256) void film_kernel(const float* sig32, const float* wcat, const float* bcat,
+                                                    int cols, float* film) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= cols) return;
+  const float* s = sig32 + n * 32;
+  const float* w = wcat + (size_t)c * 32;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc += w[k] * s[k];
+  film[(size_t)n * cols + c] = acc + bcat[c];
+}
+
+// ---- LN(emb[text]) (text_style.py:96-97): one wave per token
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* text, int rows, const float* emb, int dim,
+                                                        int vocab, T* out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  long id = text[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* e = emb + id * dim;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) s += e[c];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / dim;
+  float v = 0.f;
+  for (int c = lane; c < dim; c += 64) { const float d = e[c] - mean; v += d * d; }
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = rsqrtf(v / dim + 1e-6f);
+  for (int c = lane; c < dim; c += 64) out[(size_t)row * dim + c] = from_f<T>((e[c] - mean) * rstd);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void film_apply_kernel(const T* in, int rows, int dim, const float* gam,
+                                                          const float* bet, long bs, T* out, long total4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long e = i * 4;
+  const long r = e / dim;
+  const int c = (int)(e - r * dim);
+  const long b = r / rows;
+  const f32x4 x = load4(in + e);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + b * bs + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(bet + b * bs + c);
+  store4(out + e, x * ga + be);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* in, long n4, T* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  store4(out + i * 4, *reinterpret_cast<const f32x4*>(in + i * 4));
+}
+
+// ---- input_dense: Linear(2 -> C) (model.py:139)
+template <typename T>
+__global__ __launch_bounds__(256) void input_dense_kernel(const float* strokes, long rows, const float* w,
+                                                           const float* b, int C, T* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 channels of one row
+  const int per_row = C / 4;
+  const long r = i / per_row;
+  if (r >= rows) return;
+  const int c = (int)(i - r * per_row) * 4;
+  const float s0 = strokes[r * 2], s1 = strokes[r * 2 + 1];
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = w[(c + k) * 2] * s0 + w[(c + k) * 2 + 1] * s1 + b[c + k];
+  store4(out + r * C + c, v);
+}
+
+// ---- Philox4x32-10 -> two N(0,1) via Box-Muller
+DHW_DEV void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// key = seed; counter = (global sample, position in sample, iteration+1, 0): identical for any batch sharding
+DHW_DEV void normal2(uint64_t seed, int64_t sample, int pos, int iter, float& z0, float& z1) {
+  uint32_t c0 = (uint32_t)sample, c1 = (uint32_t)((uint64_t)sample >> 32), c2 = (uint32_t)pos, c3 = (uint32_t)(iter + 1);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+  const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u0));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u1, &sn, &cs);
+  z0 = rad * cs;
+  z1 = rad * sn;
+}
+
+// ---- heads (model.py:179-182) + fused scheduler step (utils/nn.py:84-87,110-112): one wave per 4 rows
+__global__ __launch_bounds__(256) void heads_kernel(const HeadsParams p) {
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const int l15 = lane & 15;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  if (row < p.rows) {
+    const float* x = p.x + row * p.C;
+    for (int c = l15 * 4; c < p.C; c += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.w_out + c);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.w_out + p.C + c);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(p.w_pen + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a0 += v[k] * w0[k]; a1 += v[k] * w1[k]; a2 += v[k] * w2[k]; }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o; o >>= 1) {
+    a0 += __shfl_xor(a0, o);
+    a1 += __shfl_xor(a1, o);
+    a2 += __shfl_xor(a2, o);
+  }
+  if (row >= p.rows || l15) return;
+  const float e0 = a0 + p.b_out[0], e1 = a1 + p.b_out[1];
+  const float pen = 1.0f / (1.0f + expf(-(a2 + p.b_pen[0])));
+  if (p.eps) { p.eps[row * 2] = e0; p.eps[row * 2 + 1] = e1; }
+  if (p.pen) p.pen[row] = pen;
+  if (p.xt) {
+    float z0 = 0.f, z1 = 0.f;
+    if (p.add_noise) {
+      if (p.z) { z0 = p.z[row * 2]; z1 = p.z[row * 2 + 1]; }
+      else normal2(p.seed_ptr[0], (int64_t)p.seed_ptr[1] + row / p.L, (int)(row % p.L), p.iter, z0, z1);
+    }
+    float x0 = p.xt[row * 2], x1 = p.xt[row * 2 + 1];
+    // same operation order as the reference, no FMA contraction
+    if (p.mode == 0) {   // new: (xt - sqrt(1-abar)*eps)/sqrt(1-beta) + z*sqrt(1-abar_next)
+      x0 = __fdiv_rn(__fsub_rn(x0, __fmul_rn(p.k0, e0)), p.k1);
+      x1 = __fdiv_rn(__fsub_rn(x1, __fmul_rn(p.k0, e1)), p.k1);
+      if (p.add_noise) { x0 = __fadd_rn(x0, __fmul_rn(z0, p.k2)); x1 = __fadd_rn(x1, __fmul_rn(z1, p.k2)); }
+    } else {             // standard: (1/sqrt(1-beta)) * (xt - beta*eps/sqrt(1-abar)) [+ sqrt(beta)*z]
+      x0 = __fmul_rn(p.k1, __fsub_rn(x0, __fdiv_rn(__fmul_rn(p.k3, e0), p.k0)));
+      x1 = __fmul_rn(p.k1, __fsub_rn(x1, __fdiv_rn(__fmul_rn(p.k3, e1), p.k0)));
+      if (p.add_noise) { x0 = __fadd_rn(x0, __fmul_rn(p.k2, z0)); x1 = __fadd_rn(x1, __fmul_rn(p.k2, z1)); }
+    }
+    p.xt[row * 2] = x0;
+    p.xt[row * 2 + 1] = x1;
+    if (p.out3) { p.out3[row * 3] = x0; p.out3[row * 3 + 1] = x1; p.out3[row * 3 + 2] = pen; }
+  }
+}
+
+__global__ void set_seed_kernel(uint64_t* p, uint64_t seed, int64_t first) {
+  p[0] = seed;
+  p[1] = (uint64_t)first;
+}
+
+__global__ __launch_bounds__(256) void randn_init_kernel(float* xt, long rows, int L, const uint64_t* seed_ptr) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float z0, z1;
+  normal2(seed_ptr[0], (int64_t)seed_ptr[1] + row / L, (int)(row % L), -1, z0, z1);
+  xt[row * 2] = z0;
+  xt[row * 2 + 1] = z1;
+}
+
+inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t launch_sigma_ffn(const float* sigma, int n, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* sig32, hipStream_t st) {
+  hipLaunchKernelGGL(sigma_ffn_kernel, dim3(n), dim3(256), 0, st, sigma, w1, b1, w2, b2, sig32);
+  return hipGetLastError();
+}
+hipError_t launch_film(const float* sig32, int n, const float* wcat, const float* bcat, int cols, float* film,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(film_kernel, dim3(nblk(cols, 256), n), dim3(256), 0, st, sig32, wcat, bcat, cols, film);
+  return hipGetLastError();
+}
+hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int vocab, void* out,
+                           hipStream_t st) {
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, vocab, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, vocab, (float*)out);
+  return hipGetLastError();
+}
+hipError_t launch_film_apply(int prec, const void* in, int B, int rows, int dim, const float* gam, const float* bet,
+                             long bs, void* out, hipStream_t st) {
+  const long total4 = (long)B * rows * dim / 4;
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(film_apply_kernel<bf16_t>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const bf16_t*)in, rows, dim, gam, bet, bs, (bf16_t*)out, total4);
+  else
+    hipLaunchKernelGGL(film_apply_kernel<float>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const float*)in, rows, dim, gam, bet, bs, (float*)out, total4);
+  return hipGetLastError();
+}
+hipError_t launch_cast(int prec, const float* in, long n, void* out, hipStream_t st) {
+  const long n4 = n / 4;
+  if (prec == PREC_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(nblk(n4, 256)), dim3(256), 0, st, in, n4, (bf16_t*)out);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(nblk(n4, 256)), dim3(256), 0, st, in, n4, (float*)out);
+  return hipGetLastError();
+}
+hipError_t launch_input_dense(int prec, const float* strokes, long rows, const float* w, const float* b, int C,
+                              void* out, hipStream_t st) {
+  const long n = rows * (C / 4);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(input_dense_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, st, strokes, rows, w, b, C, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(input_dense_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, st, strokes, rows, w, b, C, (float*)out);
+  return hipGetLastError();
+}
+hipError_t launch_heads(const HeadsParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(heads_kernel, dim3(nblk(p.rows, 16)), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(randn_init_kernel, dim3(nblk(rows, 256)), dim3(256), 0, st, xt, rows, L, seed_ptr);
+  return hipGetLastError();
+}
+hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st) {
+  hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, st, seed_ptr, seed, first_sample);
+  return hipGetLastError();
+}

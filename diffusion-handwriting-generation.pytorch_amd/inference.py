@@ -1,0 +1,72 @@
+"""The reverse-diffusion sampler: ``sample`` is the body of the reference's ``infer``
+loop (reference inference.py:80-96) for a whole prompt batch; ``infer`` wraps it with
+the tokenizer and the stroke-length heuristic (inference.py:65-78)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import DiffusionModel
+from .tokenizer import Tokenizer, stroke_length
+
+
+def get_beta_set(T: int = 60) -> torch.Tensor:
+    """beta_i = 0.02 + exp(linspace(ln 1e-5, ln 0.4, T)) (reference utils/nn.py:19-39); host-only."""
+    return torch.from_numpy(_lib.schedule(T)[0])
+
+
+def get_alpha_set(T: int = 60) -> torch.Tensor:
+    """abar = cumprod(1 - beta) (reference inference.py:81)."""
+    return torch.from_numpy(_lib.schedule(T)[1])
+
+
+def sample(model: DiffusionModel, text: torch.Tensor, style_vector: torch.Tensor, L: int | None = None, T: int = 60,
+           diffusion_mode: str = "new", noise: torch.Tensor | None = None, seed: int = 0,
+           first_sample: int = 0) -> torch.Tensor:
+    """Reverse-sample a batch.  text int [B,Lt] (0 = pad), style_vector [B,S,1280] -> [B,L,3] = (dx, dy, pen).
+
+    ``noise`` (optional, f32 [T+1,B,L,2]): noise[0] = x_T, noise[1+k] = the N(0,1) draw of the k-th loop
+    iteration (the reference draws them from torch's global RNG, inference.py:82 / utils/nn.py:86,111).
+    Without it the library draws from a counter-based generator keyed by (seed, first_sample + b,
+    iteration, position), so any sharding of a prompt batch over GPUs yields the same samples.
+    """
+    if diffusion_mode not in ("new", "standard"):
+        raise ValueError("diffusion_mode must be 'new' or 'standard'")
+    B, Lt = text.shape
+    if L is None:
+        L = stroke_length(Lt)
+    if L % 8:
+        raise ValueError("L must be a multiple of 8")
+    dev = model._device(text, style_vector)
+    h = model._ensure_handle(dev, B, L, Lt, style_vector.shape[1])
+    ret_dev = text.device
+    with torch.cuda.device(dev):
+        t = text.to(dev, torch.int64).contiguous()
+        sv = style_vector.to(dev, torch.float32).contiguous()
+        nz = None
+        if noise is not None:
+            if tuple(noise.shape) != (T + 1, B, L, 2):
+                raise ValueError(f"noise must be [T+1,B,L,2] = {(T + 1, B, L, 2)}")
+            nz = noise.to(dev, torch.float32).contiguous()
+        out = torch.empty((B, L, 3), device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev)
+        _lib.check(_lib.lib().dhw_sample(h, t.data_ptr(), sv.data_ptr(), B, L, Lt, T,
+                                         0 if diffusion_mode == "new" else 1,
+                                         nz.data_ptr() if nz is not None else None, seed, first_sample,
+                                         out.data_ptr(), C.c_void_p(stream.cuda_stream)), h)
+        # the library's graph holds raw pointers: pin the inputs to the model so they outlive the launch
+        model._last_sample_inputs = (t, sv, nz, out)
+    return out.to(ret_dev)
+
+
+def infer(prompt: str, style_vector: torch.Tensor, model: DiffusionModel, diffusion_mode: str = "new", T: int = 60,
+          seed: int = 0) -> np.ndarray:
+    """Single-prompt convenience wrapper with the reference's front end: tokenise, L = 16 per token rounded up
+    to a multiple of 8, sample, return the [L,3] stroke array that the reference hands to ``show_strokes``."""
+    ids = Tokenizer().encode(prompt)
+    text = torch.tensor([ids], dtype=torch.int64)
+    out = sample(model, text, style_vector, L=stroke_length(len(ids)), T=T, diffusion_mode=diffusion_mode, seed=seed)
+    return out[0].detach().cpu().numpy()

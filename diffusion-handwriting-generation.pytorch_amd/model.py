@@ -1,0 +1,182 @@
+"""``DiffusionModel`` — host-side mirror of the reference's denoiser interface
+(reference model.py:61-182) over the C-ABI HIP library.
+
+Same constructor arguments, same ``forward(strokes, text, sigma, style_vector)
+-> (eps, pen_lifts, None)`` contract, same 323-key ``state_dict`` (torch-native
+layouts), so a reference checkpoint loads with ``load_state_dict`` and callers
+(`inference.py:89`, `tests/test_model.py:21` in the reference) work unchanged.
+All arithmetic runs in libdhw_hip.so on the GPU; PyTorch only owns the device
+buffers and the stream.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from .spec import param_spec
+
+
+class _Node(nn.Module):
+    """Name-space container so parameters keep the reference's dotted keys."""
+
+
+def _torch_dtype_code(t: torch.Tensor) -> int:
+    return {torch.float32: _lib.DHW_F32, torch.bfloat16: _lib.DHW_BF16, torch.float16: _lib.DHW_F16,
+            torch.float64: _lib.DHW_F64}[t.dtype]
+
+
+class DiffusionModel(nn.Module):
+    """Diffusion denoiser conditioned on text and style (inference path, MI355X)."""
+
+    def __init__(self, num_layers: int = 4, c1: int = 128, c2: int = 192, c3: int = 256, drop_rate: float = 0.1,
+                 *, precision: str = "bf16", max_B: int = 64, max_L: int = 1000, max_Lt: int = 64, style_rows: int = 14):
+        super().__init__()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.num_layers, self.c1, self.c2, self.c3 = num_layers, c1, c2, c3
+        self.drop_rate = drop_rate  # kept for signature parity; dropout is identity on the sampling path (eval)
+        self.precision = precision
+        self._cap = dict(max_B=max_B, max_L=max_L, max_Lt=max_Lt, S=style_rows)
+        self._handle = None
+        self._handle_dev = None
+        self._wtoken = None
+        for name, shape, kind in param_spec(num_layers, c1, c2, c3):
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(self._init(shape, kind), requires_grad=False))
+
+    # torch-default-like init (nn.Linear / nn.Conv1d: U(+-1/sqrt(fan_in)); nn.Embedding: N(0,1);
+    # gamma_emb.bias = 1, conditioning.py:13)
+    @staticmethod
+    def _init(shape, kind):
+        if kind == "ones":
+            return torch.ones(shape)
+        if kind == "normal":
+            return torch.randn(shape)
+        fan_in = math.prod(shape[1:]) if kind in ("linear_w", "conv_w") else int(kind.split(":")[1])
+        bound = 1.0 / math.sqrt(fan_in)
+        return torch.empty(shape).uniform_(-bound, bound)
+
+    # ------------------------------------------------------------------ handle management
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.lib().dhw_destroy(self._handle)
+            self._handle = None
+            self._wtoken = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _device(self, *tensors) -> torch.device:
+        for t in tensors:
+            if t.is_cuda:
+                return t.device
+        p = next(self.parameters())
+        if p.is_cuda:
+            return p.device
+        if not torch.cuda.is_available():
+            raise RuntimeError("DiffusionModel needs an MI355X (HIP device): there is no CPU path in this package")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _ensure_handle(self, dev: torch.device, B: int, L: int, Lt: int, S: int):
+        cap = self._cap
+        grow = B > cap["max_B"] or L > cap["max_L"] or Lt > cap["max_Lt"] or S != cap["S"]
+        if self._handle is not None and (grow or self._handle_dev != dev):
+            self._destroy()
+        if self._handle is None:
+            cap.update(max_B=max(B, cap["max_B"]), max_L=max(L, cap["max_L"]), max_Lt=max(Lt, cap["max_Lt"]), S=S)
+            dims = _lib.DhwDims(self.num_layers, self.c1, self.c2, self.c3, cap["max_B"], cap["max_L"], cap["max_Lt"],
+                                cap["S"], _lib.PREC_F32 if self.precision == "fp32" else _lib.PREC_BF16)
+            h = C.c_void_p()
+            _lib.check(_lib.lib().dhw_create(C.byref(h), C.byref(dims), dev.index or 0))
+            self._handle, self._handle_dev = h, dev
+        token = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if token != self._wtoken:
+            self._push_weights()
+            self._wtoken = token
+        return self._handle
+
+    def _push_weights(self):
+        l = _lib.lib()
+        for k, v in self.state_dict().items():
+            t = v.detach().to("cpu").contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(l.dhw_load(self._handle, k.encode(), C.c_void_p(t.data_ptr()), _torch_dtype_code(t), shape, t.dim()),
+                       self._handle)
+        _lib.check(l.dhw_finalize(self._handle), self._handle)
+
+    # ------------------------------------------------------------------ forward == reference model.py:121-182
+    def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style_vector: torch.Tensor):
+        """strokes [B,T,2], text int [B,Lt] (0 = pad), sigma [B,1] or [B,1,1], style_vector [B,S,1280]
+        -> (eps [B,T,2] fp32, pen_lifts [B,T] fp32 in (0,1), None)."""
+        if strokes.dim() != 3 or strokes.shape[-1] != 2:
+            raise ValueError("strokes must be [B, T, 2]")
+        B, L, _ = strokes.shape
+        if L % 8:
+            raise ValueError("T must be a multiple of 8 (three 2x down/up-sampling levels, reference model.py:169-175)")
+        if style_vector.dim() != 3 or (style_vector.shape[1] * style_vector.shape[2]) % 256 or style_vector.shape[2] != 1280:
+            raise ValueError("style_vector must be [B, S, 1280]")
+        if sigma.numel() != B:
+            raise ValueError("sigma must hold one value per sample ([B,1] or [B,1,1])")
+        ret_dev = strokes.device
+        dev = self._device(strokes, text, sigma, style_vector)
+        h = self._ensure_handle(dev, B, L, text.shape[1], style_vector.shape[1])
+        with torch.cuda.device(dev):
+            s = strokes.to(dev, torch.float32).contiguous()
+            t = text.to(dev, torch.int64).contiguous()
+            sg = sigma.to(dev, torch.float32).reshape(B).contiguous()
+            sv = style_vector.to(dev, torch.float32).contiguous()
+            eps = torch.empty((B, L, 2), device=dev, dtype=torch.float32)
+            pen = torch.empty((B, L), device=dev, dtype=torch.float32)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.lib().dhw_forward(h, s.data_ptr(), t.data_ptr(), sg.data_ptr(), sv.data_ptr(), B, L,
+                                              t.shape[1], eps.data_ptr(), pen.data_ptr(), C.c_void_p(st)), h)
+            # keep the inputs alive until the stream has consumed them
+            for x in (s, t, sg, sv):
+                x.record_stream(torch.cuda.current_stream(dev))
+        return eps.to(ret_dev), pen.to(ret_dev), None
+
+    # ------------------------------------------------------------------ test / measurement hooks (include/dhw_debug.h)
+    def debug_read(self, name: str) -> torch.Tensor:
+        import numpy as np
+        shape = (C.c_int64 * 3)()
+        cap = self._cap
+        buf = np.empty(cap["max_B"] * max(cap["max_L"], cap["max_Lt"], cap["S"] * 5) * 768, np.float32)
+        n = _lib.lib().dhw_debug_read(self._handle, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, shape)
+        _lib.check(int(n), self._handle)
+        return torch.from_numpy(buf[:n].reshape(shape[0], shape[1], shape[2]).copy())
+
+    def profile(self, on: bool):
+        _lib.check(_lib.lib().dhw_profile_enable(self._handle, int(on)), self._handle)
+        if on:
+            _lib.check(_lib.lib().dhw_profile_reset(self._handle), self._handle)
+
+    def profile_results(self):
+        l = _lib.lib()
+        out = []
+        for i in range(_lib.check(l.dhw_profile_count(self._handle), self._handle)):
+            lab, ms, n, fl, by = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            l.dhw_profile_get(self._handle, i, C.byref(lab), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+            out.append(dict(label=lab.value.decode(), total_ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value))
+        return out
+
+    def work(self, L: int, Lt: int):
+        """(FLOPs, block-boundary bytes) of one denoiser call per sample."""
+        fl, by = C.c_double(), C.c_double()
+        _lib.check(_lib.lib().dhw_work(self._handle, L, Lt, C.byref(fl), C.byref(by)), self._handle)
+        return fl.value, by.value
+
+
+# BASELINE.json's north_star calls the class DiffusionWriter; the reference's symbol is DiffusionModel.
+DiffusionWriter = DiffusionModel

@@ -1,0 +1,35 @@
+/* dhw_debug.h — test / measurement hooks of libdhw_hip.so (not part of the
+ * drop-in boundary; used by tests/ and bench.py only). */
+#ifndef DHW_DEBUG_H
+#define DHW_DEBUG_H
+
+#include "dhw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Copy the named intermediate activation of the LAST dhw_forward call to the
+ * host as fp32, C-last [B, rows, cols].  Names follow the reference's module
+ * names ("enc1", "enc3", "att_layers.0", "text_style_model", "skip_conv3",
+ * "sigma_ffn", "input_dense", "att_dense", ...).  Synchronises the device.
+ * Returns the number of floats written, or a negative dhw_status. */
+int64_t dhw_debug_read(dhw_handle*, const char* name, float* host_dst, int64_t max_floats,
+                       int64_t shape_out[3]);
+
+/* Per-kernel timing: when enabled every launch is bracketed by HIP events on
+ * the launch stream (graph replay is disabled while profiling). */
+int dhw_profile_enable(dhw_handle*, int on);
+int dhw_profile_reset(dhw_handle*);
+/* Resolve pending events; returns the number of distinct kernel labels. */
+int dhw_profile_count(dhw_handle*);
+int dhw_profile_get(dhw_handle*, int i, const char** label, double* total_ms, int64_t* launches,
+                    double* flops_per_launch_sum, double* bytes_per_launch_sum);
+
+/* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
+int dhw_set_graph(dhw_handle*, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
