@@ -181,10 +181,15 @@ struct dhw_handle {
   std::vector<ProfRec> prof_recs;
   std::vector<ProfAgg> prof_agg;
 
-  // graph cache for dhw_sample
+  // graph cache for dhw_sample: the graph only touches library-owned staging buffers, so it is keyed by the
+  // problem shape alone and replays for any caller pointers
   bool use_graph = true;
-  hipGraphExec_t graph_exec = nullptr;
-  std::vector<uint64_t> graph_key;
+  std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
+  int64_t* d_text_stage = nullptr;
+  float* d_style_stage = nullptr;
+  float* d_out_stage = nullptr;
+  float* d_noise_stage = nullptr;
+  size_t noise_stage_cap = 0;
   uint64_t* d_seed = nullptr;   // [seed, first_sample] read by the noise kernels
   float* d_sigma_T = nullptr;
   int film_T_ready = 0;         // T for which d_film_T currently holds the FiLM table (0 = none)
@@ -412,6 +417,9 @@ int alloc_workspace(dhw_handle* h) {
   if ((rc = dev_alloc(h, (void**)&h->d_eps, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_pen, (size_t)(B * L + SLACK_ROWS) * 4))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_seed, 16))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_text_stage, (size_t)(B * Lt + 64) * 8))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_style_stage, (size_t)(B * S5 + SLACK_ROWS) * STYLE_CH * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->d_out_stage, (size_t)(B * L + SLACK_ROWS) * 3 * 4))) return rc;
   return 0;
 }
 
@@ -830,19 +838,20 @@ int ensure_film_T(dhw_handle* h, int T) {
 }
 
 void schedule_host(int T, std::vector<float>& beta, std::vector<float>& alpha) {
-  // utils/nn.py:19-39 in fp32: torch.linspace evaluates start + step*i below the midpoint and
-  // end - step*(n-1-i) above it; then exp, + 0.02, cumprod(1 - beta) (inference.py:81).
+  // utils/nn.py:19-39 in fp32: torch.linspace evaluates fma(step, i, start) below the midpoint and
+  // fma(-step, n-1-i, end) above it (probed against torch 2.10 CPU); then exp, + 0.02,
+  // cumprod(1 - beta) (inference.py:81).
   beta.resize(T);
   alpha.resize(T);
   const float lo = (float)std::log(1e-5), hi = (float)std::log(0.4);
   const float step = T > 1 ? (hi - lo) / (float)(T - 1) : 0.f;
   const int half = T / 2;
-  float a = 1.f;
+  double a = 1.0;   // torch's CPU cumprod accumulates float inputs in double (acc_type) and rounds each output
   for (int i = 0; i < T; ++i) {
-    const float x = i < half ? lo + step * (float)i : hi - step * (float)(T - 1 - i);
+    const float x = i < half ? fmaf(step, (float)i, lo) : fmaf(-step, (float)(T - 1 - i), hi);
     beta[i] = 0.02f + expf(x);
-    a = a * (1.0f - beta[i]);
-    alpha[i] = a;
+    a = a * (double)(1.0f - beta[i]);
+    alpha[i] = (float)a;
   }
 }
 
@@ -898,7 +907,7 @@ void dhw_destroy(dhw_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipDeviceSynchronize();
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (void* p : h->allocs) hipFree(p);
   delete h;
@@ -946,7 +955,8 @@ int dhw_finalize(dhw_handle* h) {
     if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in state_dict: %s", h->spec[i].key.c_str());
   HIPCK(h, hipSetDevice(h->device));
   HIPCK(h, hipDeviceSynchronize());
-  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_key.clear(); }
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // device is idle here (synchronised above)
+  h->graphs.clear();
   const dhw_dims& d = h->dims;
   const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
   int rc;
@@ -1120,32 +1130,52 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
     if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "set_seed: %s", hipGetErrorString(e));
   }
 
+  // stage the caller's tensors into library-owned buffers (tiny D2D copies, outside the graph)
+  const size_t rows = (size_t)B * L;
+  HIPCK(h, hipMemcpyAsync(h->d_text_stage, text, (size_t)B * Lt * 8, hipMemcpyDeviceToDevice, st));
+  HIPCK(h, hipMemcpyAsync(h->d_style_stage, style, (size_t)B * h->dims.S * 1280 * 4, hipMemcpyDeviceToDevice, st));
+  const float* nz = nullptr;
+  if (noise) {
+    const size_t need = (size_t)(T + 1) * rows * 2;
+    if (need > h->noise_stage_cap) {
+      HIPCK(h, hipDeviceSynchronize());
+      for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // they captured the old staging pointer
+      h->graphs.clear();
+      if ((rc = dev_alloc(h, (void**)&h->d_noise_stage, need * 4, false))) return rc;
+      h->noise_stage_cap = need;
+    }
+    HIPCK(h, hipMemcpyAsync(h->d_noise_stage, noise, need * 4, hipMemcpyDeviceToDevice, st));
+    nz = h->d_noise_stage;
+  }
+
   const bool graph = h->use_graph && !h->prof;
   if (!graph) {
-    rc = sample_enqueue(h, text, style, B, L, Lt, T, mode, noise, out, st, beta, alpha);
+    rc = sample_enqueue(h, h->d_text_stage, h->d_style_stage, B, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    std::vector<uint64_t> key = {(uint64_t)text, (uint64_t)style, (uint64_t)noise, (uint64_t)out, (uint64_t)B,
-                                 (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode};
-    if (!h->graph_exec || key != h->graph_key) {
-      if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr)};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
       hipStream_t cs;
       HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      HIPCK(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-      rc = sample_enqueue(h, text, style, B, L, Lt, T, mode, noise, out, cs, beta, alpha);
+      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) { hipStreamDestroy(cs); return fail(h, DHW_ERR_HIP, "begin capture: %s", hipGetErrorString(e)); }
+      rc = sample_enqueue(h, h->d_text_stage, h->d_style_stage, B, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha);
       hipGraph_t g = nullptr;
-      hipError_t e = hipStreamEndCapture(cs, &g);
+      e = hipStreamEndCapture(cs, &g);
       if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+      hipGraphExec_t ex = nullptr;
       if (rc == 0) {
-        e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         if (e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph instantiate failed: %s", hipGetErrorString(e));
       }
       if (g) hipGraphDestroy(g);
       hipStreamDestroy(cs);
-      if (rc) { h->graph_exec = nullptr; return rc; }
-      h->graph_key = key;
+      if (rc) return rc;
+      it = h->graphs.emplace(key, ex).first;
     }
-    HIPCK(h, hipGraphLaunch(h->graph_exec, st));
+    HIPCK(h, hipGraphLaunch(it->second, st));
   }
+  if (rc == 0) HIPCK(h, hipMemcpyAsync(out, h->d_out_stage, rows * 3 * 4, hipMemcpyDeviceToDevice, st));
   h->last_B = B; h->last_L = L; h->last_Lt = Lt;
   return rc;
 }

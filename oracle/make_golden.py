@@ -18,6 +18,7 @@ outputs.  Weights and inputs are regenerated from seeds by
   fwd_nl4.npz    num_layers=4 (class default model.py:66), B=1 L=64 Lt=8
   taps.npz       B=1 L=136 Lt=12 (3 pad): every top-level block's output (C-last)
   loop_new.npz / loop_std.npz  B=2 L=488 T=60: x after {1,10,30,60} steps, final [B,L,3]
+  keys.json      the reference's state_dict keys + shapes for num_layers 2 and 4
   tokenizer.json known answers of Tokenizer.encode + the L heuristic (inference.py:72-78)
 """
 import importlib.util
@@ -73,6 +74,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     spec = _load_spec()
     DiffusionModel, Tokenizer, refnn = _import_reference()
+
+    # ---- state_dict inventory of the reference (names, shapes, order)
+    keys = {}
+    for nl in (2, 4):
+        keys[str(nl)] = [[k, list(v.shape)] for k, v in DiffusionModel(nl, 128, 192, 256).state_dict().items()]
+    with open(os.path.join(OUT, "keys.json"), "w") as f:
+        json.dump(keys, f)
+    if "--keys-only" in sys.argv:
+        return
 
     # ---- schedule
     beta = refnn.get_beta_set()

@@ -1,0 +1,126 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the headers
+declare, the schedule is pinned to the reference's, the state_dict inventory and tokenizer match the
+reference, and the product path fails loudly (never falls back) when no HIP device is present."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dhg_amd
+from dhg_amd import _lib, spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = set()
+    for h in ("dhw.h", "dhw_debug.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(dhw_[a-z0-9_]+)\s*\(", src))
+    return syms
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    declared = _declared_symbols()
+    assert {"dhw_create", "dhw_load", "dhw_forward", "dhw_sample", "dhw_destroy", "dhw_last_error"} <= declared
+    for s in declared:
+        assert hasattr(lib, s), f"{s} declared in include/ but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes binding and headers disagree"
+    assert b"gfx950" in lib.dhw_version()
+
+
+def test_schedule_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sched.npz"))
+    beta, alpha = _lib.schedule(60)
+    # linspace (fma on both halves) and the double-accumulated cumprod are reproduced bit for bit; torch's
+    # vectorised expf (SLEEF u10) and libm's expf may disagree in the last bit on isolated entries
+    ulp_b = np.abs(beta.view(np.int32).astype(np.int64) - g["beta"].view(np.int32).astype(np.int64))
+    ulp_a = np.abs(alpha.view(np.int32).astype(np.int64) - g["alpha"].view(np.int32).astype(np.int64))
+    assert ulp_b.max() <= 1 and (ulp_b != 0).sum() <= 2, ulp_b
+    assert ulp_a.max() <= 1 and (ulp_a != 0).sum() <= 2, ulp_a
+    assert np.allclose(dhg_amd.get_beta_set().numpy(), g["beta"], rtol=2e-7, atol=0)
+    assert np.allclose(dhg_amd.get_alpha_set().numpy(), g["alpha"], rtol=1e-6, atol=0)
+
+
+def test_schedule_generalises_in_T():
+    b60, _ = _lib.schedule(60)
+    b1000, a1000 = _lib.schedule(1000)
+    assert abs(b1000[0] - b60[0]) < 1e-7 and abs(b1000[-1] - b60[-1]) < 1e-6
+    assert np.all(np.diff(b1000) > 0) and np.all(np.diff(a1000) < 0) and np.isfinite(a1000).all()
+    assert _lib.lib().dhw_schedule(0, None, None) < 0
+
+
+@pytest.mark.parametrize("nl", [2, 4])
+def test_state_dict_inventory_matches_reference(golden_dir, nl):
+    with open(os.path.join(golden_dir, "keys.json")) as f:
+        ref = json.load(f)[str(nl)]
+    ours = [[n, list(s)] for n, s, _ in spec.param_spec(nl)]
+    assert ours == ref
+    m = dhg_amd.DiffusionModel(nl)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref
+    assert sum(p.numel() for p in m.parameters()) == (10028451 if nl == 2 else 14074275)
+    with pytest.raises(RuntimeError):  # strict load, as the reference's checkpoint loader
+        m.load_state_dict({"bogus.weight": torch.zeros(1)})
+
+
+def test_synthetic_weights_are_portable_and_order_independent():
+    a = spec.synthetic_state_dict(2, seed=0)
+    b = spec.synthetic_state_dict(4, seed=0)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k   # keyed by tensor name, not by position
+    assert np.all(a["enc1.affine1.gamma_emb.bias"] == 1)
+    assert abs(float(a["enc1.fc.weight"].max()) - 1 / np.sqrt(128)) < 1e-3
+    s0 = spec.synthetic_inputs(4, 16, 5, seed=9)
+    s1 = spec.synthetic_inputs_range(2, 2, 16, 5, seed=9)
+    for k in ("text", "style", "strokes"):
+        assert np.array_equal(s0[k][2:], s1[k])
+    assert np.array_equal(s0["noise"][:, 2:], s1["noise"])
+
+
+def test_tokenizer_known_answers(golden_dir):
+    with open(os.path.join(golden_dir, "tokenizer.json")) as f:
+        ka = json.load(f)
+    tk = dhg_amd.Tokenizer()
+    for c in ka:
+        ids = tk.encode(c["prompt"])
+        assert ids == c["ids"]
+        assert dhg_amd.stroke_length(len(ids)) == c["L"]
+    assert tk.decode(tk.encode("Hi there")[:-1]) == "Hi there"
+    assert tk.vocab_size == 73
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_a_gpu():
+    dims = _lib.DhwDims(2, 128, 192, 256, 1, 8, 1, 14, 0)
+    h = C.c_void_p()
+    rc = _lib.lib().dhw_create(C.byref(h), C.byref(dims), 0)
+    assert rc == -3 and not h.value
+    assert b"HIP device" in _lib.lib().dhw_last_error(None)
+    m = dhg_amd.DiffusionModel(2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 8, 2), torch.ones(1, 3, dtype=torch.long), torch.ones(1, 1), torch.zeros(1, 14, 1280))
+
+
+def test_create_rejects_bad_dims():
+    l = _lib.lib()
+    h = C.c_void_p()
+    for bad in (dict(c1=64), dict(c3=128), dict(c2=96), dict(max_L=10), dict(precision=7), dict(S=0)):
+        kw = dict(num_layers=2, c1=128, c2=192, c3=256, max_B=1, max_L=8, max_Lt=1, S=14, precision=0)
+        kw.update(bad)
+        assert l.dhw_create(C.byref(h), C.byref(_lib.DhwDims(**kw)), 0) == -1, bad
+    assert l.dhw_create(None, None, 0) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src and "/root/reference" not in src, f
