@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int MT = BM / WM / 16;   // activation (column) tiles per wave
   constexpr int NT = BN / WN / 16;   // channel (row) tiles per wave
   constexpr int ES = sizeof(T);
+  constexpr int D0 = (ES == 2 ? 12 : 6) / NT;       // prefetch depth: ~12 (bf16) / 6 (fp32) fragments in flight per lane
+  constexpr int D = D0 < 2 ? 2 : (D0 > 8 ? 8 : D0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -68,19 +70,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int cpr = sg.C * ES / 16;              // 16-byte chunks per row
     const int total = rows * cpr;
     const char* src = reinterpret_cast<const char*>(sg.A);
-    for (int id = tid; id < total; id += 256) {
-      const int r = id / cpr, cc = id - r * cpr;
-      const int lrow = m0 - halo + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (lrow >= 0 && lrow < p.L) {
-        v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * sg.C) * ES + (size_t)cc * 16);
+    constexpr int U = 4;   // independent 16-byte loads in flight per thread
+    for (int base = tid; base < total; base += 256 * U) {
+      uint4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int id = base + u * 256;
+        const int r = id / cpr, cc = id - r * cpr;
+        const int lrow = m0 - halo + r;
+        v[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = id < total ? lds_off[s] + r * lds_stride[s] + cc * 16 : -1;
+        if (id < total && lrow >= 0 && lrow < p.L)
+          v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * sg.C) * ES + (size_t)cc * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         if (sg.silu) {
-          T* e = reinterpret_cast<T*>(&v);
+          T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
           for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_f(to_f(e[i])));
         }
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
       }
-      *reinterpret_cast<uint4*>(smem + lds_off[s] + r * lds_stride[s] + cc * 16) = v;
     }
   }
   __syncthreads();
@@ -103,27 +115,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const T* wbase = reinterpret_cast<const T*>(sg.W) + ((size_t)ntile0 * KT * 64 + lane) * 8;
     const char* abase = smem + lds_off[s] + (row0 + l15) * lds_stride[s] + g * 8 * ES;
 
-    Frag<T> wcur[NT], wnxt[NT];
+    // Weight fragments stream L2 -> VGPRs through a D-deep register ring.  The loop body is branch-free and
+    // statically indexed so hipcc emits counted s_waitcnt vmcnt((D-1)*NT) instead of draining the queue.
+    Frag<T> wq[D][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wcur[i] = frag_load(wbase + (size_t)i * KT * 512);
-    int tap = 0, kc = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-      if (kt + 1 < KT) {
+    for (int d = 0; d < D; ++d) {
+      const int k = d < KT ? d : KT - 1;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) wnxt[i] = frag_load(wbase + ((size_t)i * KT + kt + 1) * 512);
-      }
+      for (int i = 0; i < NT; ++i) wq[d][i] = frag_load(wbase + ((size_t)i * KT + k) * 512);
+    }
+    int aoff = 0, kc = 0;                       // LDS byte offset of the current k-chunk: tap*stride + kc*32*ES
+    const int tap_step = lds_stride[s] - (KC - 1) * 32 * ES;
+    auto step = [&](int d, int knext) {
       Frag<T> a[MT];
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
-        a[j] = frag_load(reinterpret_cast<const T*>(abase + (j * 16 + tap) * lds_stride[s] + kc * 32 * ES));
+      for (int j = 0; j < MT; ++j) a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * lds_stride[s] + aoff));
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) mma32(acc[i][j], wcur[i], a[j]);
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], wq[d][i], a[j]);
+      const int kn = knext < KT ? knext : KT - 1;   // clamped: the last D re-loads are harmless
 #pragma unroll
-      for (int i = 0; i < NT; ++i) wcur[i] = wnxt[i];
-      if (++kc == KC) { kc = 0; ++tap; }
+      for (int i = 0; i < NT; ++i) wq[d][i] = frag_load(wbase + ((size_t)i * KT + kn) * 512);
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+    int kt = 0;
+    for (; kt + D <= KT; kt += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) step(d, kt + d + D);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (kt + d < KT) step(d, KT - 1);
 
     if (s == 0 && p.nseg == 2) {
       // between the segments: acc = FiLM(acc + bias0) (ConvBlock: affine3(fc(.)), cnn.py:81-82)
