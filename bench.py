@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--streams", type=int, default=0, help="concurrent prompt sub-batches per GPU (0 = library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,6 +82,8 @@ def main():
         return dhg_amd.sample(model, text, style, L=L, T=T, seed=1000 + k, first_sample=rank * B)
 
     out = None
+    if args.streams:
+        os.environ["DHW_STREAMS"] = str(args.streams)
     if args.no_graph:
         one_step(0)
         _lib.lib().dhw_set_graph(model._handle, 0)

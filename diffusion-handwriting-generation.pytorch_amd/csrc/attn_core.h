@@ -1,0 +1,89 @@
+// attn_core.h — one wave, 16 queries of one (sample, head): softmax(QK^T/sqrt(D) + mask·(-1e9)) V
+// (reference attention.py:26-46).  Shared by the stand-alone attention kernel (attn.hip) and the fused
+// EncoderLayer kernels (enclayer.hip).  No LDS, no barrier:
+//
+//   S^T = K · Q^T      MFMA A-operand = K rows  (16 keys x D, straight from L2)
+//                      MFMA B-operand = Q rows  (16 queries x D, fragments supplied by the caller)
+//        -> lane (query = lane&15) holds keys 4g..4g+3 of each 16-key tile: softmax statistics are
+//           per lane + two cross-group shuffles.
+//   O^T = V^T · P^T    B-operand = P^T taken from the S^T accumulators IN PLACE (k-slot order: tile0 keys
+//                      4g..4g+3, tile1 keys 16+4g..); A-operand = V^T read with the SAME slot order
+//                      from the key-contiguous Vt buffer the projection GEMM wrote.
+//   Online softmax over 32-key blocks, fp32 statistics, exact for any Lk.
+#pragma once
+#include "dhw_common.h"
+
+// krow : K + (first key row)*ldk + head column offset, already advanced by (lane&15)*ldk
+// vrow : Vt + (head row offset + lane&15)*lpad + 4*(lane>>4)
+// trow : int64 token ids of this sample (key k masked iff trow[k] == 0) or nullptr
+// o[t] : on return O^T tile t (d = 16t + 4g + r, query = lane&15), already divided by the softmax sum
+template <typename T, int D>
+DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int ldk, const T* vrow, int lpad,
+                         const int64_t* trow, int Lk, f32x4 (&o)[D / 16]) {
+  constexpr int DT = D / 16, KCH = (D + 31) / 32;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const float scale = rsqrtf((float)D);
+  float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = (f32x4){0, 0, 0, 0};
+  for (int kb = 0; kb < Lk; kb += 32) {
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) {
+        const int d = 32 * c + 8 * g;
+        Frag<T> kf = d < D ? frag_load(krow + (size_t)(kb + 16 * t) * ldk + d) : frag_zero<T>();
+        mma32(s[t], kf, qf[c]);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 16 * t + 4 * g + r;
+        float v = s[t][r] * scale;
+        if (key < Lk) {
+          if (trow && trow[key] == 0) v += -1e9f;   // attention.py:44
+        } else {
+          v = -INFINITY;
+        }
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);       // finite: every block has >= 1 real key
+    const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first block
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[t][r] - m_new);
+        s[t][r] = e;
+        psum += e;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    Frag<T> pf;
+    frag_from_f32(pf, s[0], s[1]);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const T* vp = vrow + (size_t)(16 * t) * lpad + kb;
+      const f32x4 v0 = load4(vp), v1 = load4(vp + 16);
+      Frag<T> vf;
+      frag_from_f32(vf, v0, v1);
+      o[t] = o[t] * alpha;
+      mma32(o[t], vf, pf);
+    }
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = o[t] * inv;
+}

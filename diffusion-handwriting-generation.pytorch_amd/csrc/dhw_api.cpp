@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -121,6 +122,14 @@ struct ProfAgg { std::string label; double ms = 0, flops = 0, bytes = 0; int64_t
 
 struct Tap { void* p; int rows; int cols; bool f32; };
 
+// One full activation workspace.  dhw_sample splits a prompt batch into independent sub-batches, each
+// with its own workspace on its own (captured) stream, so several small kernels are in flight at once.
+struct Workspace {
+  std::map<std::string, void*> buf;
+  float* d_xt = nullptr;   // fp32 sampler state [B*L, 2]
+};
+constexpr int MAX_STREAMS = 8;
+
 // one ConvBlock / EncoderLayer worth of packed weights
 struct ConvBlockW {
   void *w_c1, *w_c2, *w_fc, *w_skip;
@@ -167,13 +176,15 @@ struct dhw_handle {
   float *b_sf1, *b_sf3, *b_q8, *b_kv8, *b_d8, *b_tf1, *b_tf3, *b_attd, *b_sk1, *b_sk2, *b_sk3;
   int f_ts1, f_ts2, f_ts3, f_ts4;
 
-  // workspace
-  std::map<std::string, void*> buf;
+  // workspaces (ws[0] serves dhw_forward; dhw_sample uses ws[0..nstreams))
+  std::vector<Workspace> ws;
+  // sub-batches dhw_sample forks onto side streams (<= nstreams_alloc).  Default 1: on ROCm 7.2 parallel
+  // hipGraph branches replay serially, and the split only shrinks every launch (measured 65 -> 99 ms at 4).
+  int nstreams = 1;
+  int nstreams_alloc = 1;
+  hipStream_t sub_streams[MAX_STREAMS] = {};
   std::map<std::string, Tap> taps;
   int lpadT = 0, lpadS = 0, lpadX[3] = {0, 0, 0};
-  float* d_xt = nullptr;
-  float* d_eps = nullptr;
-  float* d_pen = nullptr;
 
   // profiling
   bool prof = false;
@@ -184,6 +195,7 @@ struct dhw_handle {
   // graph cache for dhw_sample: the graph only touches library-owned staging buffers, so it is keyed by the
   // problem shape alone and replays for any caller pointers
   bool use_graph = true;
+  bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
   float* d_style_stage = nullptr;
@@ -357,23 +369,23 @@ int pack_enclayer(dhw_handle* h, const std::string& n, int d, int heads, float p
   return 0;
 }
 
-int act_alloc(dhw_handle* h, const std::string& name, long rows, int cols, bool f32 = false) {
+int act_alloc(dhw_handle* h, Workspace& w, const std::string& name, long rows, int cols, bool f32 = false) {
   void* p;
   const size_t bytes = (size_t)(rows + SLACK_ROWS) * cols * (f32 ? 4 : h->es);
   int rc = dev_alloc(h, &p, bytes, true);
   if (rc) return rc;
-  h->buf[name] = p;
+  w.buf[name] = p;
   return 0;
 }
 
 int pad32(int x) { return ((x + 31) / 32) * 32; }
 
-int alloc_workspace(dhw_handle* h) {
+int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
   const dhw_dims& d = h->dims;
-  const long B = d.max_B, L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
+  const long L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
   const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
   int rc;
-#define AA(name, rows, cols) if ((rc = act_alloc(h, name, rows, cols))) return rc
+#define AA(name, rows, cols) if ((rc = act_alloc(h, w, name, rows, cols))) return rc
   AA("sty_in", B * S5, STYLE_CH); AA("sty_h", B * S5, 4 * c2); AA("sty_n", B * S5, dt); AA("s1", B * S5, dt);
   AA("k8", B * S5, dt);
   AA("t_n", B * Lt, dt); AA("t1", B * Lt, dt); AA("q8", B * Lt, dt); AA("a8", B * Lt, dt); AA("t2", B * Lt, dt);
@@ -388,7 +400,7 @@ int alloc_workspace(dhw_handle* h) {
   for (const CB& c : cbs) {
     AA(std::string(c.n) + ".h1", B * c.rows, c.cout / 2);
     AA(std::string(c.n) + ".h2", B * c.rows, c.cout);
-    if (std::string(c.n) == "dec1") { if ((rc = act_alloc(h, "dec1", B * c.rows, c.cout, true))) return rc; }
+    if (std::string(c.n) == "dec1") { if ((rc = act_alloc(h, w, "dec1", B * c.rows, c.cout, true))) return rc; }
     else AA(c.n, B * c.rows, c.cout);
   }
   AA("enc1.pool", B * L / 2, c1);
@@ -410,12 +422,17 @@ int alloc_workspace(dhw_handle* h) {
   AA("att_dense", B * L / 8, dt);
   AA("xd3", B * L / 4, dt); AA("xd2", B * L / 2, c3); AA("xd1", B * L, c2);
 #undef AA
+  if ((rc = dev_alloc(h, (void**)&w.d_xt, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
+  return 0;
+}
+
+int alloc_shared(dhw_handle* h) {
+  const dhw_dims& d = h->dims;
+  const long B = d.max_B, L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
+  int rc;
   if ((rc = dev_alloc(h, (void**)&h->d_sigma_in, B * 4))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_sig32, B * SIG * 4))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_film, (size_t)B * 2 * h->film_tot * 4))) return rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_xt, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_eps, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_pen, (size_t)(B * L + SLACK_ROWS) * 4))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_seed, 16))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_text_stage, (size_t)(B * Lt + 64) * 8))) return rc;
   if ((rc = dev_alloc(h, (void**)&h->d_style_stage, (size_t)(B * S5 + SLACK_ROWS) * STYLE_CH * 4))) return rc;
@@ -461,6 +478,7 @@ struct Launch {
 // ---------------------------------------------------------------- the denoiser launch sequence
 struct Ctx {
   dhw_handle* h;
+  Workspace* ws;
   hipStream_t st;
   int B, L, Lt, S5;
   const float* film;   // row 0 of the FiLM table to use
@@ -468,7 +486,7 @@ struct Ctx {
   int err = 0;
 };
 
-void* BUF(dhw_handle* h, const std::string& n) { return h->buf.at(n); }
+void* BUF(const Ctx& c, const std::string& n) { return c.ws->buf.at(n); }
 
 GemmParams gp_base(const Ctx& c, int L, int N) {
   GemmParams p{};
@@ -522,35 +540,54 @@ void run_attn(Ctx& c, const char* label, const AttnParams& p) {
   } while (0)
 
 void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, int cols, bool f32 = false) {
-  c.h->taps[name] = Tap{BUF(c.h, bufname), rows, cols, f32};
+  c.h->taps[name] = Tap{BUF(c, bufname), rows, cols, f32};
 }
 
 // cnn.py:64-87 as three fused GEMM launches
 void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
                 void* pool) {
   dhw_handle* h = c.h;
+  if (h->fuse) {
+    ConvBlockParams q{};
+    q.x = x; q.B = c.B; q.L = L; q.Cin = w.cin; q.Cout = w.cout;
+    q.w_c1 = w.w_c1; q.w_c2 = w.w_c2; q.w_fc = w.w_fc; q.w_skip = w.w_skip;
+    q.b_c1 = w.b_c1; q.b_c2 = w.b_c2; q.b_fc = w.b_fc; q.b_skip = w.b_skip;
+    q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot;
+    q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
+    q.out = out; q.out_f32 = out_f32; q.pool = pool;
+    if (!c.err) {
+      const double rows = (double)c.B * L;
+      Launch l(h, c.st, "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout),
+               rows * (w.cin * h->es + w.cout * (out_f32 ? 4.0 : (double)h->es) * (pool ? 1.5 : 1.0)) +
+                   (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout) * h->es);
+      hipError_t e = launch_convblock(h->prec, q, c.st);
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "convblock %s: %s", n.c_str(), hipGetErrorString(e));
+    }
+    tap(c, n, n, L, w.cout, out_f32);
+    return;
+  }
   {  // h1 = SiLU(FiLM1(conv1(SiLU(x))))
     GemmParams p = gp_base(c, L, w.cout / 2);
     p.seg[0] = GemmSeg{x, w.w_c1, w.cin, 3, 1};
     p.bias0 = w.b_c1;
     set_film(c, p, w.f1, 1);
     p.silu_out = 1;
-    p.out = BUF(h, n + ".h1");
+    p.out = BUF(c, n + ".h1");
     run_gemm(c, "convblock.conv1", p);
   }
   {  // h2 = SiLU(FiLM2(conv2(h1)))
     GemmParams p = gp_base(c, L, w.cout);
-    p.seg[0] = GemmSeg{BUF(h, n + ".h1"), w.w_c2, w.cout / 2, 3, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".h1"), w.w_c2, w.cout / 2, 3, 0};
     p.bias0 = w.b_c2;
     set_film(c, p, w.f2, 1);
     p.silu_out = 1;
-    p.out = BUF(h, n + ".h2");
+    p.out = BUF(c, n + ".h2");
     run_gemm(c, "convblock.conv2", p);
   }
   {  // out = FiLM3(fc(h2)) + conv_skip(x)
     GemmParams p = gp_base(c, L, w.cout);
     p.nseg = 2;
-    p.seg[0] = GemmSeg{BUF(h, n + ".h2"), w.w_fc, w.cout, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".h2"), w.w_fc, w.cout, 1, 0};
     p.seg[1] = GemmSeg{x, w.w_skip, w.cin, 3, 0};
     p.bias0 = w.b_fc;
     p.bias1 = w.b_skip;
@@ -569,22 +606,22 @@ void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
   const int dt = 2 * h->dims.c2;
   {  // tl = FiLM0(LN(text_dense(SiLU(text))))
     GemmParams p = gp_base(c, c.Lt, w.d);
-    p.seg[0] = GemmSeg{BUF(h, "text_out"), w.w_td, dt, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, "text_out"), w.w_td, dt, 1, 1};
     p.bias0 = w.b_td;
     p.ln = 1;
     set_film(c, p, w.f0, 1);
-    p.out = BUF(h, n + ".tl");
+    p.out = BUF(c, n + ".tl");
     run_gemm(c, "enc.text_dense", p);
   }
   {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
     GemmParams p = gp_base(c, c.Lt, 2 * w.d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".tl"), w.w_kv1, w.d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".tl"), w.w_kv1, w.d, 1, 0};
     p.bias0 = w.b_kv1;
     p.posb = w.pb_k1;
     p.posb_cols = w.d;
     p.n_store = w.d;
-    p.out = BUF(h, n + ".k1");
-    p.vt = BUF(h, n + ".vt1");
+    p.out = BUF(c, n + ".k1");
+    p.vt = BUF(c, n + ".vt1");
     p.vt_lpad = h->lpadT;
     run_gemm(c, "enc.kv_text", p);
   }
@@ -594,83 +631,107 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
                void* pool) {
   dhw_handle* h = c.h;
   const int d = w.d;
+  if (h->fuse && enclayer_supported(h->prec, d, w.heads)) {
+    EncLayerParams q{};
+    q.B = c.B; q.Lk = Lk; q.Lt = c.Lt; q.d = d; q.heads = w.heads;
+    q.x = x;
+    q.w_q1 = w.w_q1; q.w_d1 = w.w_d1; q.w_qkv2 = w.w_qkv2; q.w_d2 = w.w_d2; q.w_f1 = w.w_f1; q.w_f2 = w.w_f2;
+    q.b_q1 = w.b_q1; q.b_d1 = w.b_d1; q.b_qkv2 = w.b_qkv2; q.b_d2 = w.b_d2; q.b_f1 = w.b_f1; q.b_f2 = w.b_f2;
+    q.pb_q1 = w.pb_q1; q.pb_qk2 = w.pb_qk2;
+    q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot; q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
+    q.k1 = BUF(c, n + ".k1"); q.vt1 = BUF(c, n + ".vt1"); q.lpadT = h->lpadT; q.text = text;
+    q.x2 = BUF(c, n + ".x2"); q.qk2 = BUF(c, n + ".qk2"); q.vt2 = BUF(c, n + ".vt2"); q.lpadX = lpad;
+    q.out = BUF(c, n); q.pool = pool;
+    const double rows = (double)c.B * Lk, dd = d;
+    for (int which = 0; which < 2 && !c.err; ++which) {
+      const double fl = which == 0 ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd
+                                   : 2.0 * rows * dd * dd * 5 + 4.0 * rows * Lk * dd;
+      const double by = (which == 0 ? rows * dd * 5 : rows * dd * (5 + (pool ? 0.5 : 0.0))) * h->es + 5.0 * dd * dd * h->es;
+      Launch l(h, c.st, which == 0 ? "enc.fused_a" : "enc.fused_bc", fl, by);
+      hipError_t e = launch_enclayer(h->prec, q, which, c.st);
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "enclayer %s/%d: %s", n.c_str(), which, hipGetErrorString(e));
+    }
+    tap(c, n + ".x2", n + ".x2", Lk, d);
+    tap(c, n, n, Lk, d);
+    return;
+  }
   {  // q1 = Wq(x + PE)
     GemmParams p = gp_base(c, Lk, d);
     p.seg[0] = GemmSeg{x, w.w_q1, d, 1, 0};
     p.bias0 = w.b_q1;
     p.posb = w.pb_q1;
     p.posb_cols = d;
-    p.out = BUF(h, n + ".q1");
+    p.out = BUF(c, n + ".q1");
     run_gemm(c, "enc.q_cross", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(h, n + ".q1"); a.ldq = d;
-    a.K = BUF(h, n + ".k1"); a.ldk = d; a.koff = 0;
-    a.Vt = BUF(h, n + ".vt1"); a.lpad = h->lpadT;
+    a.Q = BUF(c, n + ".q1"); a.ldq = d;
+    a.K = BUF(c, n + ".k1"); a.ldk = d; a.koff = 0;
+    a.Vt = BUF(c, n + ".vt1"); a.lpad = h->lpadT;
     a.text = text; a.ldt = c.Lt;
-    a.out = BUF(h, n + ".a1"); a.ldo = d;
+    a.out = BUF(c, n + ".a1"); a.ldo = d;
     a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = c.Lt;
     run_attn(c, "attn.cross", a);
   }
   {  // x2 = FiLM1(LN(dense(a1))) + x
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".a1"), w.w_d1, d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".a1"), w.w_d1, d, 1, 0};
     p.bias0 = w.b_d1;
     p.ln = 1;
     set_film(c, p, w.f1, 1);
     p.res2 = x;
-    p.out = BUF(h, n + ".x2");
+    p.out = BUF(c, n + ".x2");
     run_gemm(c, "enc.dense_cross", p);
   }
   {  // q2,k2 = W(x2 + PE), v2 = Wv x2
     GemmParams p = gp_base(c, Lk, 3 * d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".x2"), w.w_qkv2, d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".x2"), w.w_qkv2, d, 1, 0};
     p.bias0 = w.b_qkv2;
     p.posb = w.pb_qk2;
     p.posb_cols = 2 * d;
     p.n_store = 2 * d;
-    p.out = BUF(h, n + ".qk2");
-    p.vt = BUF(h, n + ".vt2");
+    p.out = BUF(c, n + ".qk2");
+    p.vt = BUF(c, n + ".vt2");
     p.vt_lpad = lpad;
     run_gemm(c, "enc.qkv_self", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(h, n + ".qk2"); a.ldq = 2 * d;
-    a.K = BUF(h, n + ".qk2"); a.ldk = 2 * d; a.koff = d;
-    a.Vt = BUF(h, n + ".vt2"); a.lpad = lpad;
+    a.Q = BUF(c, n + ".qk2"); a.ldq = 2 * d;
+    a.K = BUF(c, n + ".qk2"); a.ldk = 2 * d; a.koff = d;
+    a.Vt = BUF(c, n + ".vt2"); a.lpad = lpad;
     a.text = nullptr;
-    a.out = BUF(h, n + ".a2"); a.ldo = d;
+    a.out = BUF(c, n + ".a2"); a.ldo = d;
     a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = Lk;
     run_attn(c, "attn.self", a);
   }
   {  // x3 = FiLM2(LN(x2 + dense(a2)))
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".a2"), w.w_d2, d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".a2"), w.w_d2, d, 1, 0};
     p.bias0 = w.b_d2;
-    p.res1 = BUF(h, n + ".x2");
+    p.res1 = BUF(c, n + ".x2");
     p.ln = 1;
     set_film(c, p, w.f2, 1);
-    p.out = BUF(h, n + ".x3");
+    p.out = BUF(c, n + ".x3");
     run_gemm(c, "enc.dense_self", p);
   }
   {  // f = SiLU(W1 SiLU(x3) + b1)
     GemmParams p = gp_base(c, Lk, 2 * d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".x3"), w.w_f1, d, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, n + ".x3"), w.w_f1, d, 1, 1};
     p.bias0 = w.b_f1;
     p.silu_out = 1;
-    p.out = BUF(h, n + ".f");
+    p.out = BUF(c, n + ".f");
     run_gemm(c, "enc.ffn1", p);
   }
   {  // out = FiLM3(LN(W2 f + b2 + x3))
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(h, n + ".f"), w.w_f2, 2 * d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".f"), w.w_f2, 2 * d, 1, 0};
     p.bias0 = w.b_f2;
-    p.res1 = BUF(h, n + ".x3");
+    p.res1 = BUF(c, n + ".x3");
     p.ln = 1;
     set_film(c, p, w.f3, 1);
-    p.out = BUF(h, n);
+    p.out = BUF(c, n);
     p.pool = pool;
     run_gemm(c, "enc.ffn2", p);
   }
@@ -683,24 +744,24 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
 void text_style_static(Ctx& c, const int64_t* text, const float* style) {
   dhw_handle* h = c.h;
   const int c2 = h->dims.c2, dt = 2 * c2;
-  RUN_SMALL(c, "cast.style", launch_cast(h->prec, style, (long)c.B * c.S5 * STYLE_CH, BUF(h, "sty_in"), c.st));
+  RUN_SMALL(c, "cast.style", launch_cast(h->prec, style, (long)c.B * c.S5 * STYLE_CH, BUF(c, "sty_in"), c.st));
   {
     GemmParams p = gp_base(c, c.S5, 4 * c2);
-    p.seg[0] = GemmSeg{BUF(h, "sty_in"), h->w_sf1, STYLE_CH, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, "sty_in"), h->w_sf1, STYLE_CH, 1, 1};
     p.bias0 = h->b_sf1;
     p.silu_out = 1;
-    p.out = BUF(h, "sty_h");
+    p.out = BUF(c, "sty_h");
     run_gemm(c, "style.ffn1", p);
   }
   {
     GemmParams p = gp_base(c, c.S5, dt);
-    p.seg[0] = GemmSeg{BUF(h, "sty_h"), h->w_sf3, 4 * c2, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "sty_h"), h->w_sf3, 4 * c2, 1, 0};
     p.bias0 = h->b_sf3;
     p.ln = 1;
-    p.out = BUF(h, "sty_n");
+    p.out = BUF(c, "sty_n");
     run_gemm(c, "style.ffn2_ln", p);
   }
-  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, VOCAB, BUF(h, "t_n"), c.st));
+  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, VOCAB, BUF(c, "t_n"), c.st));
 }
 
 // sigma-dependent part of TextStyleEncoder (text_style.py:94-104) + the per-layer text projections
@@ -709,59 +770,59 @@ void text_style_dynamic(Ctx& c) {
   const int c2 = h->dims.c2, dt = 2 * c2;
   const float* g = c.film;
   const float* bt = c.film + h->film_tot;
-  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(h, "sty_n"), c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, BUF(h, "s1"), c.st));
-  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(h, "t_n"), c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, BUF(h, "t1"), c.st));
+  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(c, "sty_n"), c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, BUF(c, "s1"), c.st));
+  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(c, "t_n"), c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, BUF(c, "t1"), c.st));
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(h, "t1"), h->w_q8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "t1"), h->w_q8, dt, 1, 0};
     p.bias0 = h->b_q8;
-    p.out = BUF(h, "q8");
+    p.out = BUF(c, "q8");
     run_gemm(c, "ts.q", p);
   }
   {
     GemmParams p = gp_base(c, c.S5, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(h, "s1"), h->w_kv8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "s1"), h->w_kv8, dt, 1, 0};
     p.bias0 = h->b_kv8;
     p.n_store = dt;
-    p.out = BUF(h, "k8");
-    p.vt = BUF(h, "vt8");
+    p.out = BUF(c, "k8");
+    p.vt = BUF(c, "vt8");
     p.vt_lpad = h->lpadS;
     run_gemm(c, "ts.kv", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(h, "q8"); a.ldq = dt;
-    a.K = BUF(h, "k8"); a.ldk = dt; a.koff = 0;
-    a.Vt = BUF(h, "vt8"); a.lpad = h->lpadS;
-    a.out = BUF(h, "a8"); a.ldo = dt;
+    a.Q = BUF(c, "q8"); a.ldq = dt;
+    a.K = BUF(c, "k8"); a.ldk = dt; a.koff = 0;
+    a.Vt = BUF(c, "vt8"); a.lpad = h->lpadS;
+    a.out = BUF(c, "a8"); a.ldo = dt;
     a.B = c.B; a.H = 8; a.D = dt / 8; a.Lq = c.Lt; a.Lk = c.S5;
     run_attn(c, "attn.text_style", a);
   }
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(h, "a8"), h->w_d8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "a8"), h->w_d8, dt, 1, 0};
     p.bias0 = h->b_d8;
-    p.res1 = BUF(h, "t1");
+    p.res1 = BUF(c, "t1");
     p.ln = 1;
     set_film(c, p, h->f_ts3, 1);
-    p.out = BUF(h, "t2");
+    p.out = BUF(c, "t2");
     run_gemm(c, "ts.dense", p);
   }
   {
     GemmParams p = gp_base(c, c.Lt, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(h, "t2"), h->w_tf1, dt, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, "t2"), h->w_tf1, dt, 1, 1};
     p.bias0 = h->b_tf1;
     p.silu_out = 1;
-    p.out = BUF(h, "tf_h");
+    p.out = BUF(c, "tf_h");
     run_gemm(c, "ts.ffn1", p);
   }
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(h, "tf_h"), h->w_tf3, 2 * dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "tf_h"), h->w_tf3, 2 * dt, 1, 0};
     p.bias0 = h->b_tf3;
     p.ln = 1;
     set_film(c, p, h->f_ts4, 1);
-    p.out = BUF(h, "text_out");
+    p.out = BUF(c, "text_out");
     run_gemm(c, "ts.ffn2", p);
   }
   tap(c, "text_style_model.style", "s1", c.S5, dt);
@@ -777,32 +838,32 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   dhw_handle* h = c.h;
   const dhw_dims& d = h->dims;
   const int L = c.L, dt = 2 * d.c2;
-  RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(h, "x0"), c.st));
+  RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(c, "x0"), c.st));
   tap(c, "input_dense", "x0", L, d.c1);
-  conv_block(c, "enc1", h->enc1, BUF(h, "x0"), L, BUF(h, "enc1"), false, BUF(h, "enc1.pool"));
-  conv_block(c, "enc2", h->enc2, BUF(h, "enc1.pool"), L / 2, BUF(h, "enc2"), false, nullptr);
-  enc_layer(c, "enc3", h->el[0], BUF(h, "enc2"), L / 2, h->lpadX[0], text, BUF(h, "enc3.pool"));
-  conv_block(c, "enc4", h->enc4, BUF(h, "enc3.pool"), L / 4, BUF(h, "enc4"), false, nullptr);
-  enc_layer(c, "enc5", h->el[1], BUF(h, "enc4"), L / 4, h->lpadX[1], text, BUF(h, "enc5.pool"));
+  conv_block(c, "enc1", h->enc1, BUF(c, "x0"), L, BUF(c, "enc1"), false, BUF(c, "enc1.pool"));
+  conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr);
+  enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"));
+  conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr);
+  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"));
   {
     GemmParams p = gp_base(c, L / 8, dt);
-    p.seg[0] = GemmSeg{BUF(h, "enc5.pool"), h->w_attd, d.c3, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "enc5.pool"), h->w_attd, d.c3, 1, 0};
     p.bias0 = h->b_attd;
-    p.out = BUF(h, "att_dense");
+    p.out = BUF(c, "att_dense");
     run_gemm(c, "att_dense", p);
     tap(c, "att_dense", "att_dense", L / 8, dt);
   }
-  const void* x = BUF(h, "att_dense");
+  const void* x = BUF(c, "att_dense");
   for (int i = 0; i < d.num_layers; ++i) {
     const std::string n = "att_layers." + std::to_string(i);
     enc_layer(c, n, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr);
-    x = BUF(h, n);
+    x = BUF(c, n);
   }
   struct UP { const char* name; const void* skip_in; void* w; float* b; int cin, cout, L; const void* low; const char* out; };
   const UP ups[3] = {
-      {"skip_conv3", BUF(h, "enc5"), h->w_sk3, h->b_sk3, d.c3, dt, L / 4, x, "xd3"},
-      {"skip_conv2", BUF(h, "enc3"), h->w_sk2, h->b_sk2, d.c2, d.c3, L / 2, BUF(h, "dec3"), "xd2"},
-      {"skip_conv1", BUF(h, "enc1"), h->w_sk1, h->b_sk1, d.c1, d.c2, L, BUF(h, "dec2"), "xd1"}};
+      {"skip_conv3", BUF(c, "enc5"), h->w_sk3, h->b_sk3, d.c3, dt, L / 4, x, "xd3"},
+      {"skip_conv2", BUF(c, "enc3"), h->w_sk2, h->b_sk2, d.c2, d.c3, L / 2, BUF(c, "dec3"), "xd2"},
+      {"skip_conv1", BUF(c, "enc1"), h->w_sk1, h->b_sk1, d.c1, d.c2, L, BUF(c, "dec2"), "xd1"}};
   const ConvBlockW* decs[3] = {&h->dec3, &h->dec2, &h->dec1};
   const char* dn[3] = {"dec3", "dec2", "dec1"};
   for (int i = 0; i < 3; ++i) {
@@ -812,10 +873,10 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
     p.bias0 = u.b;
     p.res2 = u.low;
     p.res2_half = 1;
-    p.out = BUF(h, u.out);
+    p.out = BUF(c, u.out);
     run_gemm(c, "skip_conv_up", p);
     tap(c, std::string(u.name) + "+up", u.out, u.L, u.cout);
-    conv_block(c, dn[i], *decs[i], BUF(h, u.out), u.L, BUF(h, dn[i]), i == 2, nullptr);
+    conv_block(c, dn[i], *decs[i], BUF(c, u.out), u.L, BUF(c, dn[i]), i == 2, nullptr);
   }
 }
 
@@ -896,7 +957,22 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   h->loaded.assign(h->spec.size(), 0);
   build_film_layout(h);
   if (hipSetDevice(device) != hipSuccess) { delete h; return fail(nullptr, DHW_ERR_HIP, "hipSetDevice failed"); }
-  int rc = alloc_workspace(h);
+  {
+    const char* e = getenv("DHW_STREAMS");
+    if (e && atoi(e) >= 1) h->nstreams = std::min(atoi(e), MAX_STREAMS);
+    h->nstreams = std::max(1, std::min(h->nstreams, d.max_B));
+    h->nstreams_alloc = h->nstreams;
+  }
+  int rc = alloc_shared(h);
+  h->ws.resize(h->nstreams);
+  // ws[0] serves dhw_forward at the full batch; the others only ever see ceil(max_B / nstreams) prompts
+  for (int i = 0; !rc && i < h->nstreams; ++i)
+    rc = alloc_workspace(h, h->ws[i], i == 0 ? d.max_B : (d.max_B + h->nstreams - 1) / h->nstreams);
+  for (int i = 1; !rc && i < h->nstreams; ++i)
+    if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
+  if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
+  if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) { g_err = h->err; dhw_destroy(h); return rc; }
   *out = h;
@@ -909,6 +985,8 @@ void dhw_destroy(dhw_handle* h) {
   hipDeviceSynchronize();
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (int i = 1; i < MAX_STREAMS; ++i)
+    if (h->sub_streams[i]) hipStreamDestroy(h->sub_streams[i]);
   for (void* p : h->allocs) hipFree(p);
   delete h;
 }
@@ -1022,7 +1100,7 @@ int dhw_finalize(dhw_handle* h) {
 
 static int launch_heads_for(Ctx& c, HeadsParams hp) {
   dhw_handle* h = c.h;
-  hp.x = (const float*)BUF(h, "dec1");
+  hp.x = (const float*)BUF(c, "dec1");
   hp.rows = (long)c.B * c.L;
   hp.C = h->dims.c1;
   hp.w_out = h->out_w; hp.b_out = h->out_b; hp.w_pen = h->pen_w; hp.b_pen = h->pen_b;
@@ -1040,7 +1118,7 @@ int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const 
   if ((rc = dhw_finalize(h))) return rc;
   HIPCK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)hip_stream;
-  Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
+  Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
   h->taps.clear();
   RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(sigma, B, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32, st));
   RUN_SMALL(c, "film_table", launch_film(h->d_sig32, B, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film, st));
@@ -1056,31 +1134,37 @@ int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const 
   return c.err;
 }
 
-static int sample_enqueue(dhw_handle* h, const int64_t* text, const float* style, int B, int L, int Lt, int T, int mode,
-                          const float* noise, float* out, hipStream_t st, const std::vector<float>& beta,
-                          const std::vector<float>& alpha) {
-  const long rows = (long)B * L;
-  Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
-  h->taps.clear();
+// One prompt sub-batch [b0, b0+Bs) of a B-prompt batch, enqueued on `st` with workspace `w`.
+static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, const int64_t* text, const float* style,
+                          int L, int Lt, int T, int mode, const float* noise, float* out, hipStream_t st,
+                          const std::vector<float>& beta, const std::vector<float>& alpha) {
+  const long rows = (long)Bs * L;
+  const size_t step_stride = (size_t)B * L * 2;   // one noise draw for the whole batch
+  text += (size_t)b0 * Lt;
+  style += (size_t)b0 * h->dims.S * 1280;
+  out += (size_t)b0 * L * 3;
+  if (noise) noise += (size_t)b0 * L * 2;
+  Ctx c{h, w, st, Bs, L, Lt, h->dims.S * 5, h->d_film_T, 0};
   // x_T
   if (noise) {
-    hipError_t e = hipMemcpyAsync(h->d_xt, noise, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
+    hipError_t e = hipMemcpyAsync(w->d_xt, noise, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy x_T: %s", hipGetErrorString(e));
   } else {
-    RUN_SMALL(c, "randn_init", launch_randn_init(h->d_xt, rows, L, h->d_seed, st));
+    RUN_SMALL(c, "randn_init", launch_randn_init(w->d_xt, rows, L, h->d_seed, b0, st));
   }
   text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
   for (int step = 0, i = T - 1; i >= 0; --i, ++step) {
     c.film = h->d_film_T + (size_t)i * 2 * h->film_tot;
     text_style_dynamic(c);
-    stroke_path(c, h->d_xt, text);
+    stroke_path(c, w->d_xt, text);
     HeadsParams hp{};
     hp.eps = nullptr;
     hp.pen = nullptr;
-    hp.xt = h->d_xt;
-    hp.z = noise ? noise + (size_t)(1 + step) * rows * 2 : nullptr;
+    hp.xt = w->d_xt;
+    hp.z = noise ? noise + (size_t)(1 + step) * step_stride : nullptr;
     hp.mode = mode;
     hp.seed_ptr = h->d_seed;
+    hp.sample_off = b0;
     hp.iter = step;
     const float a = alpha[i], b = beta[i];
     const float a_next = i > 1 ? alpha[i - 1] : 1.0f;   // inference.py:87
@@ -1102,6 +1186,43 @@ static int sample_enqueue(dhw_handle* h, const int64_t* text, const float* style
   return c.err;
 }
 
+// All sub-batches of one dhw_sample call.  On a capturing stream the sub-batches fork onto the handle's
+// side streams (parallel graph branches) and join back; eagerly (profiling) they run one after another.
+static int sample_enqueue_all(dhw_handle* h, bool fork, int B, const int64_t* text, const float* style, int L, int Lt,
+                              int T, int mode, const float* noise, float* out, hipStream_t st,
+                              const std::vector<float>& beta, const std::vector<float>& alpha) {
+  const int ns = std::min(h->nstreams, B);
+  const int per = (B + ns - 1) / ns;
+  h->taps.clear();
+  if (!fork || ns == 1) {
+    for (int s = 0, b0 = 0; b0 < B; ++s, b0 += per) {
+      int rc = sample_enqueue(h, &h->ws[s], b0, std::min(per, B - b0), B, text, style, L, Lt, T, mode, noise, out, st, beta, alpha);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  hipEvent_t fork_ev, join_ev[MAX_STREAMS] = {};
+  if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return fail(h, DHW_ERR_HIP, "event create failed");
+  int rc = 0;
+  if (hipEventRecord(fork_ev, st) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "fork record failed");
+  for (int s = 1, b0 = per; !rc && b0 < B; ++s, b0 += per) {
+    hipStream_t ss = h->sub_streams[s];
+    if (hipStreamWaitEvent(ss, fork_ev, 0) != hipSuccess) { rc = fail(h, DHW_ERR_HIP, "fork wait failed"); break; }
+    rc = sample_enqueue(h, &h->ws[s], b0, std::min(per, B - b0), B, text, style, L, Lt, T, mode, noise, out, ss, beta, alpha);
+    if (rc) break;
+    if (hipEventCreateWithFlags(&join_ev[s], hipEventDisableTiming) != hipSuccess || hipEventRecord(join_ev[s], ss) != hipSuccess)
+      rc = fail(h, DHW_ERR_HIP, "join record failed");
+  }
+  if (!rc) rc = sample_enqueue(h, &h->ws[0], 0, std::min(per, B), B, text, style, L, Lt, T, mode, noise, out, st, beta, alpha);
+  for (int s = 1; s < MAX_STREAMS; ++s)
+    if (join_ev[s]) {
+      if (!rc && hipStreamWaitEvent(st, join_ev[s], 0) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "join wait failed");
+      hipEventDestroy(join_ev[s]);
+    }
+  hipEventDestroy(fork_ev);
+  return rc;
+}
+
 int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, int L, int Lt, int T, int mode,
                const float* noise, uint64_t seed, int64_t first_sample, float* out, void* hip_stream) {
   if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
@@ -1119,7 +1240,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if (h->film_T_ready != T) {
     // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]
     HIPCK(h, hipMemcpy(h->d_sigma_T, sig.data(), T * 4, hipMemcpyHostToDevice));
-    Ctx c{h, st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
+    Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
     RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(h->d_sigma_T, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32_T, st));
     RUN_SMALL(c, "film_table", launch_film(h->d_sig32_T, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film_T, st));
     if (c.err) return c.err;
@@ -1150,16 +1271,16 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
 
   const bool graph = h->use_graph && !h->prof;
   if (!graph) {
-    rc = sample_enqueue(h, h->d_text_stage, h->d_style_stage, B, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
+    rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr)};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipStream_t cs;
       HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
       if (e != hipSuccess) { hipStreamDestroy(cs); return fail(h, DHW_ERR_HIP, "begin capture: %s", hipGetErrorString(e)); }
-      rc = sample_enqueue(h, h->d_text_stage, h->d_style_stage, B, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha);
+      rc = sample_enqueue_all(h, true, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha);
       hipGraph_t g = nullptr;
       e = hipStreamEndCapture(cs, &g);
       if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
@@ -1273,6 +1394,11 @@ int dhw_profile_get(dhw_handle* h, int i, const char** label, double* total_ms, 
   if (flops_sum) *flops_sum = a.flops;
   if (bytes_sum) *bytes_sum = a.bytes;
   return 0;
+}
+int dhw_set_streams(dhw_handle* h, int n) {
+  if (!h || n < 1) return DHW_ERR_ARG;
+  h->nstreams = std::min(n, h->nstreams_alloc);
+  return h->nstreams;
 }
 int dhw_set_graph(dhw_handle* h, int on) {
   if (!h) return DHW_ERR_ARG;

@@ -47,6 +47,38 @@ hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st);
 // tile actually chosen (for tests / work accounting)
 void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN);
 
+// ---------------------------------------------------------------- fused ConvBlock (cnn.py:64-87), one launch
+struct ConvBlockParams {
+  const void* x;                      // block input [B*L, Cin]
+  int B, L, Cin, Cout;
+  const void *w_c1, *w_c2, *w_fc, *w_skip;     // packed as for the GEMM kernel
+  const float *b_c1, *b_c2, *b_fc, *b_skip;
+  const float* film; long film_bs; int film_tot;   // gamma row = film + b*film_bs, beta row = gamma + film_tot
+  int f1, f2, f3;                     // FiLM offsets of affine1..3
+  void* out; int out_f32;             // [B*L, Cout]
+  void* pool;                         // optional AvgPool1d(2) side output [B*L/2, Cout]
+};
+hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st);
+hipError_t convblock_init();
+
+// ---------------------------------------------------------------- fused EncoderLayer stroke side (model.py:37-58), two launches
+struct EncLayerParams {
+  int B, Lk, Lt, d, heads;
+  const void* x;                                   // layer input [B*Lk, d]
+  const void *w_q1, *w_d1, *w_qkv2, *w_d2, *w_f1, *w_f2;   // packed as for the GEMM kernel
+  const float *b_q1, *b_d1, *b_qkv2, *b_d2, *b_f1, *b_f2;
+  const float *pb_q1, *pb_qk2;                     // PE·W tables [>=Lk][d], [>=Lk][2d]
+  const float* film; long film_bs; int film_tot; int f1, f2, f3;
+  const void* k1; const void* vt1; int lpadT;      // text keys [B*Lt, d], values [B][d][lpadT]
+  const int64_t* text;                             // key padding mask source [B, Lt] (0 = pad)
+  void* x2;                                        // [B*Lk, d]     written by enc_a, read by enc_bc
+  void* qk2; void* vt2; int lpadX;                 // [B*Lk, 2d], [B][d][lpadX]
+  void* out; void* pool;                           // [B*Lk, d], optional [B*Lk/2, d]
+};
+bool enclayer_supported(int prec, int d, int heads);
+hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st);
+hipError_t enclayer_init();
+
 // ---------------------------------------------------------------- attention
 struct AttnParams {
   const void* Q; int ldq;      // Q[(b*Lq + q)*ldq + h*D + d]
@@ -92,12 +124,12 @@ struct HeadsParams {
   float k1;                // new: sqrt(1 - beta_i);  standard: 1 / sqrt(1 - beta_i)
   float k2;                // new: sqrt(1 - abar_next);  standard: sqrt(beta_i)
   float k3;                // standard: beta_i
-  const uint64_t* seed_ptr; int L; int iter;   // Philox: device [seed, first_sample]; counter = (sample, pos, iter)
+  const uint64_t* seed_ptr; int sample_off; int L; int iter;   // Philox: device [seed, first_sample]; counter = (sample, pos, iter)
   float* out3;             // optional [rows,3] final cat(x, pen)
 };
 hipError_t launch_heads(const HeadsParams& p, hipStream_t st);
 // x_T ~ N(0,1) from Philox, same keying as the per-step draws (iter = -1)
-hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, hipStream_t st);
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st);
 // seed_ptr[0] = seed, seed_ptr[1] = first_sample (by-value kernel arguments: no host buffer lifetime)
 hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st);
 // one-time per-process kernel attribute setup (dynamic LDS > 64 KiB)

@@ -1,0 +1,343 @@
+// enclayer.hip — the stroke side of one EncoderLayer (reference model.py:37-58) in TWO launches instead of
+// eight.  A workgroup (8 waves) owns 64 stroke rows of one sample; every intermediate of its rows lives in
+// LDS.  The only hand-off through global memory is the one the algorithm forces: self-attention needs the
+// K/V of ALL rows of the sample, so the layer is cut between the q/k/v projection and the attention.
+//
+//   enc_a : q1 = Wq(x+PE) -> cross-attention over the text keys -> dense -> LN -> FiLM1 -> +x = x2
+//           -> [q2|k2|v2] = W(x2 (+PE))                       (writes x2, qk2, vt2)
+//   enc_bc: self-attention(q2,k2,v2) -> dense -> +x2 -> LN -> FiLM2 = x3 -> ffn1 (SiLU) -> ffn2 -> +x3
+//           -> LN -> FiLM3 = out (+ AvgPool1d(2) side output)
+//
+// GEMM stages: waves 2 (row halves) x 4 (channel quarters), weights streamed from L2 in fragment order
+// (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
+#include "attn_core.h"
+#include "gemm_core.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+constexpr int BM = 64;
+
+template <typename T>
+DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
+  constexpr int ES = sizeof(T);
+  const int cpr = C * ES / 16;
+  const int total = BM * cpr;
+  constexpr int U = 4;
+  for (int base = tid; base < total; base += nthreads * U) {
+    uint4 v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = base + u * nthreads;
+      const int r = id / cpr, cc = id - r * cpr;
+      v[u] = make_uint4(0, 0, 0, 0);
+      off[u] = id < total ? r * S + cc * 16 : -1;
+      if (id < total && m0 + r < L)
+        v[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + ((size_t)(b * L + m0 + r) * C) * ES + (size_t)cc * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) *reinterpret_cast<uint4*>(dst + off[u]) = v[u];
+  }
+}
+
+template <typename T, int DM>
+__global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
+  constexpr int ES = sizeof(T);
+  constexpr int MT = 2, NT = DM / 64, H = DM / 64, KC = DM / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles = (p.Lk + BM - 1) / BM;
+  const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
+  const int S = tile_stride<T>(DM);
+  char* XR = smem;               // x, later x2
+  char* QR = XR + BM * S;        // q1, later a1
+  float* red = reinterpret_cast<float*>(QR + BM * S);
+  const float* gam = p.film + (size_t)b * p.film_bs;
+  const float* bet = gam + p.film_tot;
+  const int row0 = wm * 32, ntile0 = wn * NT;
+
+  stage_rows<T>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
+  __syncthreads();
+
+  {  // ---- q1 = Wq x + b + PE·Wq[row]
+    f32x4 acc[NT][MT];
+    acc_zero(acc);
+    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_q1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+                        XR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = (ntile0 + i) * 16 + 4 * g;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_q1 + n);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = row0 + j * 16 + l15;
+        const f32x4 v = acc[i][j] + bi + *reinterpret_cast<const f32x4*>(p.pb_q1 + (size_t)(m0 + r) * DM + n);
+        store4(reinterpret_cast<T*>(QR + r * S) + n, v);
+      }
+    }
+  }
+  __syncthreads();
+
+  {  // ---- cross attention over the Lt text keys; a1 overwrites q1 in place (same wave, same rows/columns)
+    const int rg = wave & 3, hs = wave >> 2;
+    const T* k1 = reinterpret_cast<const T*>(p.k1);
+    const T* vt1 = reinterpret_cast<const T*>(p.vt1);
+    for (int h = hs; h < H; h += 2) {
+      Frag<T> qf[2];
+      const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + h * 64 + 8 * g;
+      qf[0] = frag_load(qrow);
+      qf[1] = frag_load(qrow + 32);
+      f32x4 o[4];
+      attn_wave16<T, 64>(qf, k1 + (size_t)(b * p.Lt + l15) * DM + h * 64, DM,
+                         vt1 + ((size_t)b * DM + h * 64 + l15) * p.lpadT + 4 * g, p.lpadT,
+                         p.text ? p.text + (size_t)b * p.Lt : nullptr, p.Lt, o);
+      T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
+    }
+  }
+  __syncthreads();
+
+  {  // ---- x2 = FiLM1(LN(Wd a1 + b)) + x
+    f32x4 acc[NT][MT];
+    acc_zero(acc);
+    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_d1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+                        QR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_d1 + (ntile0 + i) * 16 + 4 * g);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] += bi;
+    }
+    layernorm_rows<MT, NT, 4, BM>(acc, red, wn, row0, lane, DM);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = (ntile0 + i) * 16 + 4 * g;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f1 + n);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f1 + n);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = row0 + j * 16 + l15;
+        T* xp = reinterpret_cast<T*>(XR + r * S) + n;
+        const f32x4 v = acc[i][j] * ga + be + load4(xp);
+        store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
+        if (m0 + r < p.Lk) store4(reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0 + r) * DM + n, v);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time
+  for (int chunk = 0; chunk < 3; ++chunk) {
+    f32x4 acc[NT][MT];
+    acc_zero(acc);
+    const int nt = chunk * (DM / 16) + ntile0;
+    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_qkv2) + ((size_t)nt * KC * 64 + lane) * 8,
+                        XR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int nl = (ntile0 + i) * 16 + 4 * g;       // column inside the chunk
+      const int n = chunk * DM + nl;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_qkv2 + n);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = m0 + row0 + j * 16 + l15;
+        f32x4 v = acc[i][j] + bi;
+        if (chunk < 2) {
+          if (r < p.Lk) {
+            v += *reinterpret_cast<const f32x4*>(p.pb_qk2 + (size_t)r * 2 * DM + n);
+            store4(reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + r) * 2 * DM + n, v);
+          }
+        } else if (r < p.lpadX) {   // V: key-contiguous for the PV product; rows past Lk stay zero
+          T* vt = reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + nl) * p.lpadX + r;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) vt[(size_t)k * p.lpadX] = from_f<T>(r < p.Lk ? v[k] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int DM>
+__global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
+  constexpr int ES = sizeof(T);
+  constexpr int MT = 2, NT = DM / 64, H = DM / 64, KC = DM / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles = (p.Lk + BM - 1) / BM;
+  const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
+  const int S = tile_stride<T>(DM);
+  char* R1 = smem;               // a2, later SiLU(x3)
+  char* R2 = R1 + BM * S;        // x3
+  char* R3 = R2 + BM * S;        // one DM-wide half of the FFN hidden layer
+  float* red = reinterpret_cast<float*>(R3 + BM * S);
+  const float* gam = p.film + (size_t)b * p.film_bs;
+  const float* bet = gam + p.film_tot;
+  const int row0 = wm * 32, ntile0 = wn * NT;
+
+  {  // ---- self attention: q2, k2 from qk2, v2 from vt2 (all rows of the sample) -> a2 in LDS
+    const int rg = wave & 3, hs = wave >> 2;
+    const T* qk = reinterpret_cast<const T*>(p.qk2);
+    const T* vt2 = reinterpret_cast<const T*>(p.vt2);
+    for (int h = hs; h < H; h += 2) {
+      Frag<T> qf[2];
+      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + h * 64 + 8 * g;
+      qf[0] = frag_load(qrow);
+      qf[1] = frag_load(qrow + 32);
+      f32x4 o[4];
+      attn_wave16<T, 64>(qf, qk + (size_t)(b * p.Lk + l15) * 2 * DM + DM + h * 64, 2 * DM,
+                         vt2 + ((size_t)b * DM + h * 64 + l15) * p.lpadX + 4 * g, p.lpadX, nullptr, p.Lk, o);
+      T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
+    }
+  }
+  __syncthreads();
+
+  {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
+    f32x4 acc[NT][MT];
+    acc_zero(acc);
+    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_d2) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+                        R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = (ntile0 + i) * 16 + 4 * g;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_d2 + n);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = m0 + row0 + j * 16 + l15;
+        acc[i][j] += bi;
+        if (r < p.Lk) acc[i][j] += load4(reinterpret_cast<const T*>(p.x2) + (size_t)(b * p.Lk + r) * DM + n);
+      }
+    }
+    layernorm_rows<MT, NT, 4, BM>(acc, red, wn, row0, lane, DM);   // its barriers also fence the a2 reads above
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = (ntile0 + i) * 16 + 4 * g;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f2 + n);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f2 + n);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = row0 + j * 16 + l15;
+        f32x4 v = acc[i][j] * ga + be;
+        store4(reinterpret_cast<T*>(R2 + r * S) + n, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+        store4(reinterpret_cast<T*>(R1 + r * S) + n, v);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out = FiLM3(LN(W2 SiLU(W1 SiLU(x3) + b1) + b2 + x3)); the 2*DM hidden layer is processed in two halves
+  f32x4 acc2[NT][MT];
+  acc_zero(acc2);
+  for (int hh = 0; hh < 2; ++hh) {
+    {
+      f32x4 acc[NT][MT];
+      acc_zero(acc);
+      const int nt = hh * (DM / 16) + ntile0;
+      mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_f1) + ((size_t)nt * KC * 64 + lane) * 8,
+                          R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int nl = (ntile0 + i) * 16 + 4 * g;
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_f1 + hh * DM + nl);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          f32x4 v = acc[i][j] + bi;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+          store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + nl, v);
+        }
+      }
+    }
+    __syncthreads();
+    // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]
+    mainloop<T, MT, NT>(acc2, reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8,
+                        R3 + (row0 + l15) * S + g * 8 * ES, S, KC, 1, 2 * KC);
+    __syncthreads();   // R3 is rewritten by the next half
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (ntile0 + i) * 16 + 4 * g;
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_f2 + n);
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      acc2[i][j] += bi + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n);
+  }
+  layernorm_rows<MT, NT, 4, BM>(acc2, red, wn, row0, lane, DM);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (ntile0 + i) * 16 + 4 * g;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f3 + n);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f3 + n);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int r = m0 + row0 + j * 16 + l15;
+      const bool valid = r < p.Lk;
+      const f32x4 v = acc2[i][j] * ga + be;
+      if (valid) store4(reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + r) * DM + n, v);
+      if (p.pool) {
+        f32x4 q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = 0.5f * (v[k] + __shfl_xor(v[k], 1));
+        if (valid && !(lane & 1))
+          store4(reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + (r >> 1)) * DM + n, q);
+      }
+    }
+  }
+}
+
+template <typename T, int DM>
+hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
+  const int tiles = (p.Lk + BM - 1) / BM;
+  const size_t red = 2 * 4 * BM * sizeof(float);
+  if (which == 0) {
+    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red;
+    hipLaunchKernelGGL((enc_a_kernel<T, DM>), dim3(p.B * tiles), dim3(512), lds, st, p);
+  } else {
+    const size_t lds = (size_t)3 * BM * tile_stride<T>(DM) + red;
+    hipLaunchKernelGGL((enc_bc_kernel<T, DM>), dim3(p.B * tiles), dim3(512), lds, st, p);
+  }
+  return hipGetLastError();
+}
+
+template <typename T, int DM>
+hipError_t attr() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bc_kernel<T, DM>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace
+
+hipError_t enclayer_init() {
+  hipError_t e;
+  if ((e = attr<bf16_t, 192>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 256>()) != hipSuccess) return e;
+  return attr<bf16_t, 384>();
+}
+
+bool enclayer_supported(int prec, int d, int heads) {
+  return prec == PREC_BF16 && (d == 192 || d == 256 || d == 384) && heads * 64 == d;
+}
+
+// which: 0 = enc_a (cross attention half + q/k/v projection), 1 = enc_bc (self attention + FFN half)
+hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st) {
+  if (!enclayer_supported(prec, p.d, p.heads) || (p.pool && (p.Lk & 1))) return hipErrorInvalidValue;
+  switch (p.d) {
+    case 192: return launch_pair<bf16_t, 192>(p, which, st);
+    case 256: return launch_pair<bf16_t, 256>(p, which, st);
+    case 384: return launch_pair<bf16_t, 384>(p, which, st);
+  }
+  return hipErrorInvalidValue;
+}

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsParams p) {
     float z0 = 0.f, z1 = 0.f;
     if (p.add_noise) {
       if (p.z) { z0 = p.z[row * 2]; z1 = p.z[row * 2 + 1]; }
-      else normal2(p.seed_ptr[0], (int64_t)p.seed_ptr[1] + row / p.L, (int)(row % p.L), p.iter, z0, z1);
+      else normal2(p.seed_ptr[0], (int64_t)p.seed_ptr[1] + p.sample_off + row / p.L, (int)(row % p.L), p.iter, z0, z1);
     }
     float x0 = p.xt[row * 2], x1 = p.xt[row * 2 + 1];
     // same operation order as the reference, no FMA contraction
@@ -182,11 +182,11 @@ __global__ void set_seed_kernel(uint64_t* p, uint64_t seed, int64_t first) {
   p[1] = (uint64_t)first;
 }
 
-__global__ __launch_bounds__(256) void randn_init_kernel(float* xt, long rows, int L, const uint64_t* seed_ptr) {
+__global__ __launch_bounds__(256) void randn_init_kernel(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off) {
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   float z0, z1;
-  normal2(seed_ptr[0], (int64_t)seed_ptr[1] + row / L, (int)(row % L), -1, z0, z1);
+  normal2(seed_ptr[0], (int64_t)seed_ptr[1] + sample_off + row / L, (int)(row % L), -1, z0, z1);
   xt[row * 2] = z0;
   xt[row * 2 + 1] = z1;
 }
@@ -241,8 +241,8 @@ hipError_t launch_heads(const HeadsParams& p, hipStream_t st) {
   hipLaunchKernelGGL(heads_kernel, dim3(nblk(p.rows, 16)), dim3(256), 0, st, p);
   return hipGetLastError();
 }
-hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, hipStream_t st) {
-  hipLaunchKernelGGL(randn_init_kernel, dim3(nblk(rows, 256)), dim3(256), 0, st, xt, rows, L, seed_ptr);
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st) {
+  hipLaunchKernelGGL(randn_init_kernel, dim3(nblk(rows, 256)), dim3(256), 0, st, xt, rows, L, seed_ptr, sample_off);
   return hipGetLastError();
 }
 hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st) {

@@ -26,6 +26,10 @@ int dhw_profile_count(dhw_handle*);
 int dhw_profile_get(dhw_handle*, int i, const char** label, double* total_ms, int64_t* launches,
                     double* flops_per_launch_sum, double* bytes_per_launch_sum);
 
+/* Number of prompt sub-batches dhw_sample runs concurrently (parallel graph branches on side streams);
+ * clamped to the count allocated at create (env DHW_STREAMS, default 1).  Returns the value in effect. */
+int dhw_set_streams(dhw_handle*, int n);
+
 /* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
 int dhw_set_graph(dhw_handle*, int on);
 
