@@ -14,15 +14,14 @@
 //                      slot order from the key-contiguous Vt buffer the
 //                      projection GEMM wrote.
 //   Online softmax over 32-key blocks (fp32 statistics), exact for any Lk.
-#include "dhw_common.h"
+#include "attn_core.h"
 #include "dhw_kernels.h"
 
 namespace {
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
-  constexpr int DT = D / 16;          // output d-tiles
-  constexpr int KCH = (D + 31) / 32;  // k-chunks of the QK^T contraction
+  constexpr int DT = D / 16, KCH = (D + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -30,9 +29,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   if (q0 >= p.Lq) return;   // wave-uniform
 
   const T* Q = reinterpret_cast<const T*>(p.Q);
-  const T* K = reinterpret_cast<const T*>(p.K);
-  const T* Vt = reinterpret_cast<const T*>(p.Vt);
-
   // Q fragments (B operand): query q0+l15, d = 32c + 8g .. +8; d >= D is zero (D = 48)
   Frag<T> qf[KCH];
 #pragma unroll
@@ -40,81 +36,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int d = 32 * c + 8 * g;
     qf[c] = d < D ? frag_load(Q + (size_t)(b * p.Lq + q0 + l15) * p.ldq + h * D + d) : frag_zero<T>();
   }
-
-  const float scale = rsqrtf((float)D);
-  float m_run = -INFINITY, l_run = 0.f;   // per query (= per lane column); l_run is this lane-group's partial sum
   f32x4 o[DT];
-#pragma unroll
-  for (int t = 0; t < DT; ++t) o[t] = (f32x4){0, 0, 0, 0};
-
-  const T* krow = K + (size_t)(b * p.Lk + l15) * p.ldk + p.koff + h * D;
-  const T* vrow = Vt + ((size_t)(b * p.H + h) * D + l15) * p.lpad + 4 * g;
-  const int64_t* trow = p.text ? p.text + (size_t)b * p.ldt : nullptr;
-
-  for (int kb = 0; kb < p.Lk; kb += 32) {
-    f32x4 s[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      s[t] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-      for (int c = 0; c < KCH; ++c) {
-        const int d = 32 * c + 8 * g;
-        Frag<T> kf = d < D ? frag_load(krow + (size_t)(kb + 16 * t) * p.ldk + d) : frag_zero<T>();
-        mma32(s[t], kf, qf[c]);
-      }
-    }
-    // scale, key-padding mask (attention.py:44: + mask * -1e9), tail keys -> -inf
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb + 16 * t + 4 * g + r;
-        float v = s[t][r] * scale;
-        if (key < p.Lk) {
-          if (trow && trow[key] == 0) v += -1e9f;
-        } else {
-          v = -INFINITY;
-        }
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);       // finite: every block has >= 1 real key
-    const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first block
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[t][r] - m_new);
-        s[t][r] = e;
-        psum += e;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    Frag<T> pf;
-    frag_from_f32(pf, s[0], s[1]);
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      // V^T fragment: d = 16t + l15, k-slots = keys kb+4g..+3 and kb+16+4g..+3 (zero padded past Lk)
-      const T* vp = vrow + (size_t)(16 * t) * p.lpad + kb;
-      const f32x4 v0 = load4(vp), v1 = load4(vp + 16);
-      Frag<T> vf;
-      frag_from_f32(vf, v0, v1);
-      o[t] = o[t] * alpha;
-      mma32(o[t], vf, pf);
-    }
-  }
-  float l = l_run;
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
-  const float inv = 1.0f / l;
+  attn_wave16_auto<T, D>(qf, reinterpret_cast<const T*>(p.K) + (size_t)(b * p.Lk + l15) * p.ldk + p.koff + h * D, p.ldk,
+                    reinterpret_cast<const T*>(p.Vt) + ((size_t)(b * p.H + h) * D + l15) * p.lpad + 4 * g, p.lpad,
+                    p.text ? p.text + (size_t)b * p.ldt : nullptr, p.Lk, o);
   if (q0 + l15 < p.Lq) {
     T* out = reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lq + q0 + l15) * p.ldo + h * D + 4 * g;
 #pragma unroll
-    for (int t = 0; t < DT; ++t) store4(out + 16 * t, o[t] * inv);
+    for (int t = 0; t < DT; ++t) store4(out + 16 * t, o[t]);
   }
 }
 

@@ -17,30 +17,47 @@
 // vrow : Vt + (head row offset + lane&15)*lpad + 4*(lane>>4)
 // trow : int64 token ids of this sample (key k masked iff trow[k] == 0) or nullptr
 // o[t] : on return O^T tile t (d = 16t + 4g + r, query = lane&15), already divided by the softmax sum
-template <typename T, int D>
+// KB = keys per block (32, 64 or 128).  All K and V^T operands of a block are requested up front, so a block
+// costs ONE L2/MALL round trip and its MFMAs / exps are independent; the serial part per block (max/sum
+// shuffles, rescale) is amortised over KB keys.  Keys past Lk are masked to -inf (P = 0 exactly); the V^T rows
+// are zero/finite-padded by the producer, the K rows past Lk are never used unmasked.
+template <typename T, int D, int KB>
 DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int ldk, const T* vrow, int lpad,
                          const int64_t* trow, int Lk, f32x4 (&o)[D / 16]) {
-  constexpr int DT = D / 16, KCH = (D + 31) / 32;
+  constexpr int DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const float scale = rsqrtf((float)D);
   float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
   for (int t = 0; t < DT; ++t) o[t] = (f32x4){0, 0, 0, 0};
-  for (int kb = 0; kb < Lk; kb += 32) {
-    f32x4 s[2];
+  for (int kb = 0; kb < Lk; kb += KB) {
+    Frag<T> kf[NTILE][KCH];
+    Frag<T> vf[DT][NPF];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      s[t] = (f32x4){0, 0, 0, 0};
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
       for (int c = 0; c < KCH; ++c) {
         const int d = 32 * c + 8 * g;
-        Frag<T> kf = d < D ? frag_load(krow + (size_t)(kb + 16 * t) * ldk + d) : frag_zero<T>();
-        mma32(s[t], kf, qf[c]);
+        kf[t][c] = d < D ? frag_load(krow + (size_t)(kb + 16 * t) * ldk + d) : frag_zero<T>();
       }
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int pp = 0; pp < NPF; ++pp) {
+        const T* vp = vrow + (size_t)(16 * t) * lpad + kb + 32 * pp;
+        vf[t][pp] = frag_load_halves(vp, vp + 16);
+      }
+    __builtin_amdgcn_sched_barrier(0);   // keep every operand request of the block ahead of the math
+    f32x4 s[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      s[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) mma32(s[t], kf[t][c], qf[c]);
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kb + 16 * t + 4 * g + r;
@@ -59,7 +76,7 @@ DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int 
     const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first block
     float psum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(s[t][r] - m_new);
@@ -68,16 +85,14 @@ DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int 
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    Frag<T> pf;
-    frag_from_f32(pf, s[0], s[1]);
+    Frag<T> pf[NPF];
+#pragma unroll
+    for (int pp = 0; pp < NPF; ++pp) frag_from_f32(pf[pp], s[2 * pp], s[2 * pp + 1]);
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
-      const T* vp = vrow + (size_t)(16 * t) * lpad + kb;
-      const f32x4 v0 = load4(vp), v1 = load4(vp + 16);
-      Frag<T> vf;
-      frag_from_f32(vf, v0, v1);
       o[t] = o[t] * alpha;
-      mma32(o[t], vf, pf);
+#pragma unroll
+      for (int pp = 0; pp < NPF; ++pp) mma32(o[t], vf[t][pp], pf[pp]);
     }
   }
   float l = l_run;
@@ -86,4 +101,13 @@ DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int 
   const float inv = 1.0f / l;
 #pragma unroll
   for (int t = 0; t < DT; ++t) o[t] = o[t] * inv;
+}
+
+// block size by key count: one block whenever the keys fit
+template <typename T, int D>
+DHW_DEV void attn_wave16_auto(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int ldk, const T* vrow, int lpad,
+                              const int64_t* trow, int Lk, f32x4 (&o)[D / 16]) {
+  if (Lk <= 32) attn_wave16<T, D, 32>(qf, krow, ldk, vrow, lpad, trow, Lk, o);
+  else if (Lk <= 64) attn_wave16<T, D, 64>(qf, krow, ldk, vrow, lpad, trow, Lk, o);
+  else attn_wave16<T, D, 128>(qf, krow, ldk, vrow, lpad, trow, Lk, o);
 }

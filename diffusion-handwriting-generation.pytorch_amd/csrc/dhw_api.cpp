@@ -127,6 +127,8 @@ struct Tap { void* p; int rows; int cols; bool f32; };
 struct Workspace {
   std::map<std::string, void*> buf;
   float* d_xt = nullptr;   // fp32 sampler state [B*L, 2]
+  long cap_B = 0;          // prompts this workspace was sized for
+  long plane_cap = 0;      // (steps x prompts) the all-steps text plane (".T" buffers) is sized for
 };
 constexpr int MAX_STREAMS = 8;
 
@@ -195,6 +197,7 @@ struct dhw_handle {
   // graph cache for dhw_sample: the graph only touches library-owned staging buffers, so it is keyed by the
   // problem shape alone and replays for any caller pointers
   bool use_graph = true;
+  bool plane = true;            // all-steps text plane in dhw_sample (env DHW_PLANE=0 -> text side inside every step)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
@@ -381,6 +384,7 @@ int act_alloc(dhw_handle* h, Workspace& w, const std::string& name, long rows, i
 int pad32(int x) { return ((x + 31) / 32) * 32; }
 
 int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
+  w.cap_B = B;
   const dhw_dims& d = h->dims;
   const long L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
   const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
@@ -423,6 +427,27 @@ int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
   AA("xd3", B * L / 4, dt); AA("xd2", B * L / 2, c3); AA("xd1", B * L, c2);
 #undef AA
   if ((rc = dev_alloc(h, (void**)&w.d_xt, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
+  return 0;
+}
+
+// All-steps text plane: every sigma-dependent text-side activation for `steps` sampler steps x `B` prompts.
+int ensure_plane(dhw_handle* h, Workspace& w, long steps, long B) {
+  if (steps * B <= w.plane_cap) return 0;
+  const dhw_dims& d = h->dims;
+  const long n = steps * B, Lt = d.max_Lt, S5 = d.S * 5;
+  const int c2 = d.c2, c3 = d.c3, dt = 2 * c2;
+  int rc;
+#define AA(name, rows, cols) if ((rc = act_alloc(h, w, name, rows, cols))) return rc
+  AA("s1.T", n * S5, dt); AA("k8.T", n * S5, dt); AA("vt8.T", n * dt, h->lpadS);
+  AA("t1.T", n * Lt, dt); AA("q8.T", n * Lt, dt); AA("a8.T", n * Lt, dt); AA("t2.T", n * Lt, dt);
+  AA("tf_h.T", n * Lt, 2 * dt); AA("text_out.T", n * Lt, dt);
+  std::vector<std::pair<std::string, int>> els = {{"enc3", c2}, {"enc5", c3}};
+  for (int i = 0; i < d.num_layers; ++i) els.push_back({"att_layers." + std::to_string(i), dt});
+  for (auto& e : els) {
+    AA(e.first + ".tl.T", n * Lt, e.second); AA(e.first + ".k1.T", n * Lt, e.second); AA(e.first + ".vt1.T", n * e.second, h->lpadT);
+  }
+#undef AA
+  w.plane_cap = n;   // (a grown plane leaks the smaller one until destroy)
   return 0;
 }
 
@@ -482,8 +507,13 @@ struct Ctx {
   hipStream_t st;
   int B, L, Lt, S5;
   const float* film;   // row 0 of the FiLM table to use
-  long film_bs;        // batch stride (0 in the sampling loop)
+  long film_bs;        // FiLM row stride (0 in the sampling loop)
   int err = 0;
+  int film_div = 1;    // samples per FiLM row
+  int in_B = 0;        // batch of the sigma-independent inputs (0 = B); the text plane replicates them over steps
+  std::string sfx;     // suffix of the text-side output buffers: "" (per call) or ".T" (all-steps plane)
+  bool use_plane = false;   // stroke path reads the text K/V of step `plane_step` from the plane
+  long plane_step = 0;
 };
 
 void* BUF(const Ctx& c, const std::string& n) { return c.ws->buf.at(n); }
@@ -496,6 +526,7 @@ GemmParams gp_base(const Ctx& c, int L, int N) {
   p.N = N;
   p.n_store = N;
   p.film_bs = c.film_bs;
+  p.film_div = c.film_div;
   return p;
 }
 void set_film(const Ctx& c, GemmParams& p, int off, int mode) {
@@ -606,22 +637,22 @@ void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
   const int dt = 2 * h->dims.c2;
   {  // tl = FiLM0(LN(text_dense(SiLU(text))))
     GemmParams p = gp_base(c, c.Lt, w.d);
-    p.seg[0] = GemmSeg{BUF(c, "text_out"), w.w_td, dt, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, "text_out" + c.sfx), w.w_td, dt, 1, 1};
     p.bias0 = w.b_td;
     p.ln = 1;
     set_film(c, p, w.f0, 1);
-    p.out = BUF(c, n + ".tl");
+    p.out = BUF(c, n + ".tl" + c.sfx);
     run_gemm(c, "enc.text_dense", p);
   }
   {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
     GemmParams p = gp_base(c, c.Lt, 2 * w.d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".tl"), w.w_kv1, w.d, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, n + ".tl" + c.sfx), w.w_kv1, w.d, 1, 0};
     p.bias0 = w.b_kv1;
     p.posb = w.pb_k1;
     p.posb_cols = w.d;
     p.n_store = w.d;
-    p.out = BUF(c, n + ".k1");
-    p.vt = BUF(c, n + ".vt1");
+    p.out = BUF(c, n + ".k1" + c.sfx);
+    p.vt = BUF(c, n + ".vt1" + c.sfx);
     p.vt_lpad = h->lpadT;
     run_gemm(c, "enc.kv_text", p);
   }
@@ -631,6 +662,13 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
                void* pool) {
   dhw_handle* h = c.h;
   const int d = w.d;
+  // text keys/values of this layer: per-call buffers, or step `plane_step` of the all-steps plane
+  const char* k1p = (const char*)BUF(c, n + (c.use_plane ? ".k1.T" : ".k1"));
+  const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
+  if (c.use_plane) {
+    k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
+    vt1p += (size_t)c.plane_step * c.B * d * h->lpadT * h->es;
+  }
   if (h->fuse && enclayer_supported(h->prec, d, w.heads)) {
     EncLayerParams q{};
     q.B = c.B; q.Lk = Lk; q.Lt = c.Lt; q.d = d; q.heads = w.heads;
@@ -639,7 +677,7 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
     q.b_q1 = w.b_q1; q.b_d1 = w.b_d1; q.b_qkv2 = w.b_qkv2; q.b_d2 = w.b_d2; q.b_f1 = w.b_f1; q.b_f2 = w.b_f2;
     q.pb_q1 = w.pb_q1; q.pb_qk2 = w.pb_qk2;
     q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot; q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
-    q.k1 = BUF(c, n + ".k1"); q.vt1 = BUF(c, n + ".vt1"); q.lpadT = h->lpadT; q.text = text;
+    q.k1 = k1p; q.vt1 = vt1p; q.lpadT = h->lpadT; q.text = text;
     q.x2 = BUF(c, n + ".x2"); q.qk2 = BUF(c, n + ".qk2"); q.vt2 = BUF(c, n + ".vt2"); q.lpadX = lpad;
     q.out = BUF(c, n); q.pool = pool;
     const double rows = (double)c.B * Lk, dd = d;
@@ -667,8 +705,8 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
   {
     AttnParams a{};
     a.Q = BUF(c, n + ".q1"); a.ldq = d;
-    a.K = BUF(c, n + ".k1"); a.ldk = d; a.koff = 0;
-    a.Vt = BUF(c, n + ".vt1"); a.lpad = h->lpadT;
+    a.K = k1p; a.ldk = d; a.koff = 0;
+    a.Vt = vt1p; a.lpad = h->lpadT;
     a.text = text; a.ldt = c.Lt;
     a.out = BUF(c, n + ".a1"); a.ldo = d;
     a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = c.Lt;
@@ -770,64 +808,68 @@ void text_style_dynamic(Ctx& c) {
   const int c2 = h->dims.c2, dt = 2 * c2;
   const float* g = c.film;
   const float* bt = c.film + h->film_tot;
-  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(c, "sty_n"), c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, BUF(c, "s1"), c.st));
-  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(c, "t_n"), c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, BUF(c, "t1"), c.st));
+  const std::string& x = c.sfx;
+  const int in_B = c.in_B ? c.in_B : c.B;
+  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(c, "sty_n"), in_B, c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, c.film_div, BUF(c, "s1" + x), c.st));
+  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(c, "t_n"), in_B, c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, c.film_div, BUF(c, "t1" + x), c.st));
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "t1"), h->w_q8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "t1" + x), h->w_q8, dt, 1, 0};
     p.bias0 = h->b_q8;
-    p.out = BUF(c, "q8");
+    p.out = BUF(c, "q8" + x);
     run_gemm(c, "ts.q", p);
   }
   {
     GemmParams p = gp_base(c, c.S5, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(c, "s1"), h->w_kv8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "s1" + x), h->w_kv8, dt, 1, 0};
     p.bias0 = h->b_kv8;
     p.n_store = dt;
-    p.out = BUF(c, "k8");
-    p.vt = BUF(c, "vt8");
+    p.out = BUF(c, "k8" + x);
+    p.vt = BUF(c, "vt8" + x);
     p.vt_lpad = h->lpadS;
     run_gemm(c, "ts.kv", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(c, "q8"); a.ldq = dt;
-    a.K = BUF(c, "k8"); a.ldk = dt; a.koff = 0;
-    a.Vt = BUF(c, "vt8"); a.lpad = h->lpadS;
-    a.out = BUF(c, "a8"); a.ldo = dt;
+    a.Q = BUF(c, "q8" + x); a.ldq = dt;
+    a.K = BUF(c, "k8" + x); a.ldk = dt; a.koff = 0;
+    a.Vt = BUF(c, "vt8" + x); a.lpad = h->lpadS;
+    a.out = BUF(c, "a8" + x); a.ldo = dt;
     a.B = c.B; a.H = 8; a.D = dt / 8; a.Lq = c.Lt; a.Lk = c.S5;
     run_attn(c, "attn.text_style", a);
   }
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "a8"), h->w_d8, dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "a8" + x), h->w_d8, dt, 1, 0};
     p.bias0 = h->b_d8;
-    p.res1 = BUF(c, "t1");
+    p.res1 = BUF(c, "t1" + x);
     p.ln = 1;
     set_film(c, p, h->f_ts3, 1);
-    p.out = BUF(c, "t2");
+    p.out = BUF(c, "t2" + x);
     run_gemm(c, "ts.dense", p);
   }
   {
     GemmParams p = gp_base(c, c.Lt, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(c, "t2"), h->w_tf1, dt, 1, 1};
+    p.seg[0] = GemmSeg{BUF(c, "t2" + x), h->w_tf1, dt, 1, 1};
     p.bias0 = h->b_tf1;
     p.silu_out = 1;
-    p.out = BUF(c, "tf_h");
+    p.out = BUF(c, "tf_h" + x);
     run_gemm(c, "ts.ffn1", p);
   }
   {
     GemmParams p = gp_base(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "tf_h"), h->w_tf3, 2 * dt, 1, 0};
+    p.seg[0] = GemmSeg{BUF(c, "tf_h" + x), h->w_tf3, 2 * dt, 1, 0};
     p.bias0 = h->b_tf3;
     p.ln = 1;
     set_film(c, p, h->f_ts4, 1);
-    p.out = BUF(c, "text_out");
+    p.out = BUF(c, "text_out" + x);
     run_gemm(c, "ts.ffn2", p);
   }
-  tap(c, "text_style_model.style", "s1", c.S5, dt);
-  tap(c, "text_style_model.t2", "t2", c.Lt, dt);
-  tap(c, "text_style_model", "text_out", c.Lt, dt);
+  if (x.empty()) {
+    tap(c, "text_style_model.style", "s1", c.S5, dt);
+    tap(c, "text_style_model.t2", "t2", c.Lt, dt);
+    tap(c, "text_style_model", "text_out", c.Lt, dt);
+  }
   const char* names[2] = {"enc3", "enc5"};
   for (size_t i = 0; i < h->el.size(); ++i)
     enc_layer_text(c, i < 2 ? names[i] : "att_layers." + std::to_string(i - 2), h->el[i]);
@@ -971,6 +1013,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   for (int i = 1; !rc && i < h->nstreams; ++i)
     if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
   if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
+  if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1134,6 +1177,9 @@ int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const 
   return c.err;
 }
 
+// sampler steps whose text side is precomputed together (bounds the plane's memory for long schedules)
+static int plane_chunk(int T) { return std::min(T, 64); }
+
 // One prompt sub-batch [b0, b0+Bs) of a B-prompt batch, enqueued on `st` with workspace `w`.
 static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, const int64_t* text, const float* style,
                           int L, int Lt, int T, int mode, const float* noise, float* out, hipStream_t st,
@@ -1153,9 +1199,27 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
     RUN_SMALL(c, "randn_init", launch_randn_init(w->d_xt, rows, L, h->d_seed, b0, st));
   }
   text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
+  const int TC = plane_chunk(T);
   for (int step = 0, i = T - 1; i >= 0; --i, ++step) {
+    if (h->plane && step % TC == 0) {
+      // The text side (TextStyleEncoder + every layer's text K/V, text_style.py:91-104, model.py:38-42) depends on
+      // (text, style, sigma_i) only and the sigma schedule is known: evaluate it for the next `ns` steps in ONE
+      // batched pass (ns*Bs "samples", FiLM row per step) instead of 16 small launches inside every step.
+      const int ns = std::min(TC, T - step);
+      Ctx cp = c;
+      cp.B = ns * Bs;
+      cp.in_B = Bs;
+      cp.film = h->d_film_T + (size_t)i * 2 * h->film_tot;   // step `step + k` uses schedule index i - k
+      cp.film_bs = -2L * h->film_tot;
+      cp.film_div = Bs;
+      cp.sfx = ".T";
+      text_style_dynamic(cp);
+      if (cp.err) return cp.err;
+    }
     c.film = h->d_film_T + (size_t)i * 2 * h->film_tot;
-    text_style_dynamic(c);
+    c.use_plane = h->plane;
+    c.plane_step = step % TC;
+    if (!h->plane) text_style_dynamic(c);
     stroke_path(c, w->d_xt, text);
     HeadsParams hp{};
     hp.eps = nullptr;
@@ -1234,6 +1298,11 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   HIPCK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)hip_stream;
   if ((rc = ensure_film_T(h, T))) return rc;
+  if (h->plane) {
+    const int ns = std::min(h->nstreams, B), per = (B + ns - 1) / ns;
+    for (int s = 0; s < ns; ++s)
+      if ((rc = ensure_plane(h, h->ws[s], plane_chunk(T), per))) return rc;
+  }
   std::vector<float> beta, alpha, sig(T);
   schedule_host(T, beta, alpha);
   for (int i = 0; i < T; ++i) sig[i] = sqrtf(alpha[i]);   // inference.py:89
@@ -1273,7 +1342,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if (!graph) {
     rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipStream_t cs;

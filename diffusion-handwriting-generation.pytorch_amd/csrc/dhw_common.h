@@ -68,6 +68,20 @@ DHW_DEV void frag_from_f32(Frag<bf16_t>& f, const f32x4& a, const f32x4& b) {
 }
 DHW_DEV void frag_from_f32(Frag<float>& f, const f32x4& a, const f32x4& b) { f.lo = a; f.hi = b; }
 
+// fragment from two 4-element halves in memory (elements 0..3 at p0, 4..7 at p1), no conversion
+DHW_DEV Frag<bf16_t> frag_load_halves(const bf16_t* p0, const bf16_t* p1) {
+  Frag<bf16_t> f;
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0), b = *reinterpret_cast<const bf16x4*>(p1);
+  f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+DHW_DEV Frag<float> frag_load_halves(const float* p0, const float* p1) {
+  Frag<float> f;
+  f.lo = *reinterpret_cast<const f32x4*>(p0);
+  f.hi = *reinterpret_cast<const f32x4*>(p1);
+  return f;
+}
+
 // 4 consecutive elements <-> f32x4
 DHW_DEV f32x4 load4(const bf16_t* p) {
   bf16x4 v = *reinterpret_cast<const bf16x4*>(p);

@@ -26,9 +26,10 @@ struct GemmParams {
   const float* bias1;    // [N] added after segment 1 (nseg == 2) or null
   const float* posb;     // [>=L][posb_cols] position bias (PE·W), added for n < posb_cols; or null
   int posb_cols;
-  const float* gam;      // FiLM gamma/beta for this layer: gam[b*film_bs + n]
+  const float* gam;      // FiLM gamma/beta for this layer: gam[(b / film_div) * film_bs + n]
   const float* bet;
-  long film_bs;          // batch stride of the FiLM table (0 inside the sampling loop)
+  long film_bs;          // row stride of the FiLM table (0 inside the sampling loop; may be negative)
+  int film_div;          // samples sharing one FiLM row (1 = per-sample sigma; B = batched all-steps text pass)
   int film_mode;         // 0 none; 1 after (LN); 2 between segment 0 and 1 (ConvBlock: FiLM3(fc)+conv_skip)
   const void* res1;      // [B*L, N] added before LN, or null
   const void* res2;      // added after FiLM: [B*L, N], or [B*L/2, N] when res2_half (nearest x2 upsample)
@@ -74,6 +75,8 @@ struct EncLayerParams {
   void* x2;                                        // [B*Lk, d]     written by enc_a, read by enc_bc
   void* qk2; void* vt2; int lpadX;                 // [B*Lk, 2d], [B][d][lpadX]
   void* out; void* pool;                           // [B*Lk, d], optional [B*Lk/2, d]
+  int dbg;                                         // diagnostics only: bit0 = skip the attention stage (a = q)
+  unsigned long long* stamps;                      // diagnostics only: per-stage s_memrealtime of workgroup 0 (16 slots per kernel) or null
 };
 bool enclayer_supported(int prec, int d, int heads);
 hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st);
@@ -100,9 +103,9 @@ hipError_t launch_film(const float* sig32, int n, const float* wcat, const float
 // t_n = LN(emb[text])  (text_style.py:96-97), element type out
 hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int vocab,
                            void* out, hipStream_t st);
-// out[b, r, c] = in[b, r, c] * gam[b*bs + c] + bet[b*bs + c]
-hipError_t launch_film_apply(int prec, const void* in, int B, int rows, int dim, const float* gam,
-                             const float* bet, long bs, void* out, hipStream_t st);
+// out[b, r, c] = in[b % in_B, r, c] * gam[(b / div)*bs + c] + bet[(b / div)*bs + c]
+hipError_t launch_film_apply(int prec, const void* in, int in_B, int B, int rows, int dim, const float* gam,
+                             const float* bet, long bs, int div, void* out, hipStream_t st);
 // fp32 -> element type
 hipError_t launch_cast(int prec, const float* in, long n, void* out, hipStream_t st);
 // x0[b,l,:] = W[:,0]*s0 + W[:,1]*s1 + bias   (model.py:139)

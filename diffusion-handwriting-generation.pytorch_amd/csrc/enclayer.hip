@@ -8,7 +8,7 @@
 //   enc_bc: self-attention(q2,k2,v2) -> dense -> +x2 -> LN -> FiLM2 = x3 -> ffn1 (SiLU) -> ffn2 -> +x3
 //           -> LN -> FiLM3 = out (+ AvgPool1d(2) side output)
 //
-// GEMM stages: waves 2 (row halves) x 4 (channel quarters), weights streamed from L2 in fragment order
+// GEMM stages: waves WM (row groups) x WN (channel groups), weights streamed from L2 in fragment order
 // (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
 #include "attn_core.h"
 #include "gemm_core.h"
@@ -17,6 +17,12 @@
 namespace {
 
 constexpr int BM = 64;
+
+// diagnostic stage stamps (100 MHz s_memrealtime), only when the caller passes a buffer
+#define STAMP(slot)                                                                                   \
+  do {                                                                                                \
+    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 
 template <typename T>
 DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
@@ -43,13 +49,15 @@ DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int
 }
 
 template <typename T, int DM>
-__global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {
   constexpr int ES = sizeof(T);
-  constexpr int MT = 2, NT = DM / 64, H = DM / 64, KC = DM / 32;
+  constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
+  constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
+  constexpr int RING = 24;   // weight fragments in flight per wave (register budget: 256 at 2 waves/SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles = (p.Lk + BM - 1) / BM;
   const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
   const int S = tile_stride<T>(DM);
@@ -58,15 +66,17 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
   float* red = reinterpret_cast<float*>(QR + BM * S);
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
-  const int row0 = wm * 32, ntile0 = wn * NT;
+  const int row0 = wm * (BM / WM), ntile0 = wn * NT;
 
+  STAMP(0);
   stage_rows<T>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
   __syncthreads();
+  STAMP(1);
 
   {  // ---- q1 = Wq x + b + PE·Wq[row]
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_q1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_q1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
                         XR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -75,24 +85,26 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int r = row0 + j * 16 + l15;
-        const f32x4 v = acc[i][j] + bi + *reinterpret_cast<const f32x4*>(p.pb_q1 + (size_t)(m0 + r) * DM + n);
+        const f32x4 v = acc[i][j] + bi + *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + r) * DM + n));
         store4(reinterpret_cast<T*>(QR + r * S) + n, v);
       }
     }
   }
   __syncthreads();
+  STAMP(2);
 
   {  // ---- cross attention over the Lt text keys; a1 overwrites q1 in place (same wave, same rows/columns)
     const int rg = wave & 3, hs = wave >> 2;
     const T* k1 = reinterpret_cast<const T*>(p.k1);
     const T* vt1 = reinterpret_cast<const T*>(p.vt1);
+#pragma unroll 1
     for (int h = hs; h < H; h += 2) {
       Frag<T> qf[2];
       const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + h * 64 + 8 * g;
       qf[0] = frag_load(qrow);
       qf[1] = frag_load(qrow + 32);
       f32x4 o[4];
-      attn_wave16<T, 64>(qf, k1 + (size_t)(b * p.Lt + l15) * DM + h * 64, DM,
+      attn_wave16_auto<T, 64>(qf, k1 + (size_t)(b * p.Lt + l15) * DM + h * 64, DM,
                          vt1 + ((size_t)b * DM + h * 64 + l15) * p.lpadT + 4 * g, p.lpadT,
                          p.text ? p.text + (size_t)b * p.Lt : nullptr, p.Lt, o);
       T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
@@ -101,11 +113,12 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
     }
   }
   __syncthreads();
+  STAMP(3);
 
   {  // ---- x2 = FiLM1(LN(Wd a1 + b)) + x
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_d1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_d1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
                         QR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] += bi;
     }
-    layernorm_rows<MT, NT, 4, BM>(acc, red, wn, row0, lane, DM);
+    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int n = (ntile0 + i) * 16 + 4 * g;
@@ -125,22 +138,27 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
         T* xp = reinterpret_cast<T*>(XR + r * S) + n;
         const f32x4 v = acc[i][j] * ga + be + load4(xp);
         store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
-        if (m0 + r < p.Lk) store4(reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0 + r) * DM + n, v);
+        if (m0 + r < p.Lk) store4(reinterpret_cast<T*>(p.x2) + (unsigned)((b * p.Lk + m0 + r) * DM + n), v);
       }
     }
   }
   __syncthreads();
+  STAMP(4);
 
-  // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time
+  // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
+  // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
+#pragma unroll 1
   for (int chunk = 0; chunk < 3; ++chunk) {
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
     f32x4 acc[NT][MT];
     acc_zero(acc);
     const int nt = chunk * (DM / 16) + ntile0;
-    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_qkv2) + ((size_t)nt * KC * 64 + lane) * 8,
-                        XR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_qkv2) + ((size_t)nt * KC * 64 + lane) * 8,
+                              XR + (row0 + l15) * S + g * 8 * ES + opaque, S, KC, 1);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int nl = (ntile0 + i) * 16 + 4 * g;       // column inside the chunk
+      const int nl = (ntile0 + i) * 16 + 4 * g + opaque;       // column inside the chunk
       const int n = chunk * DM + nl;
       const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_qkv2 + n);
 #pragma unroll
@@ -149,27 +167,30 @@ __global__ __launch_bounds__(512) void enc_a_kernel(const EncLayerParams p) {
         f32x4 v = acc[i][j] + bi;
         if (chunk < 2) {
           if (r < p.Lk) {
-            v += *reinterpret_cast<const f32x4*>(p.pb_qk2 + (size_t)r * 2 * DM + n);
-            store4(reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + r) * 2 * DM + n, v);
+            v += *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)(r * 2 * DM + n));
+            store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + r) * 2 * DM + n), v);
           }
         } else if (r < p.lpadX) {   // V: key-contiguous for the PV product; rows past Lk stay zero
-          T* vt = reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + nl) * p.lpadX + r;
+          const unsigned vo = (unsigned)((b * DM + nl) * p.lpadX + r);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) vt[(size_t)k * p.lpadX] = from_f<T>(r < p.Lk ? v[k] : 0.f);
+          for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(p.vt2)[vo + (unsigned)(k * p.lpadX)] = from_f<T>(r < p.Lk ? v[k] : 0.f);
         }
       }
     }
+    STAMP(5 + chunk);
   }
 }
 
 template <typename T, int DM>
-__global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p) {
   constexpr int ES = sizeof(T);
-  constexpr int MT = 2, NT = DM / 64, H = DM / 64, KC = DM / 32;
+  constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
+  constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
+  constexpr int RING = DM == 384 ? 18 : 24;   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles = (p.Lk + BM - 1) / BM;
   const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
   const int S = tile_stride<T>(DM);
@@ -179,19 +200,22 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
   float* red = reinterpret_cast<float*>(R3 + BM * S);
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
-  const int row0 = wm * 32, ntile0 = wn * NT;
+  const int row0 = wm * (BM / WM), ntile0 = wn * NT;
 
+  STAMP(16);
   {  // ---- self attention: q2, k2 from qk2, v2 from vt2 (all rows of the sample) -> a2 in LDS
     const int rg = wave & 3, hs = wave >> 2;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
     const T* vt2 = reinterpret_cast<const T*>(p.vt2);
+#pragma unroll 1
     for (int h = hs; h < H; h += 2) {
+      if (p.dbg & 1) break;
       Frag<T> qf[2];
       const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + h * 64 + 8 * g;
       qf[0] = frag_load(qrow);
       qf[1] = frag_load(qrow + 32);
       f32x4 o[4];
-      attn_wave16<T, 64>(qf, qk + (size_t)(b * p.Lk + l15) * 2 * DM + DM + h * 64, 2 * DM,
+      attn_wave16_auto<T, 64>(qf, qk + (size_t)(b * p.Lk + l15) * 2 * DM + DM + h * 64, 2 * DM,
                          vt2 + ((size_t)b * DM + h * 64 + l15) * p.lpadX + 4 * g, p.lpadX, nullptr, p.Lk, o);
       T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
 #pragma unroll
@@ -199,11 +223,12 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
     }
   }
   __syncthreads();
+  STAMP(17);
 
   {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_d2) + ((size_t)ntile0 * KC * 64 + lane) * 8,
+    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_d2) + ((size_t)ntile0 * KC * 64 + lane) * 8,
                         R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -213,10 +238,11 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
       for (int j = 0; j < MT; ++j) {
         const int r = m0 + row0 + j * 16 + l15;
         acc[i][j] += bi;
-        if (r < p.Lk) acc[i][j] += load4(reinterpret_cast<const T*>(p.x2) + (size_t)(b * p.Lk + r) * DM + n);
+        if (r < p.Lk) acc[i][j] += load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n));
       }
     }
-    layernorm_rows<MT, NT, 4, BM>(acc, red, wn, row0, lane, DM);   // its barriers also fence the a2 reads above
+    STAMP(18);
+    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);   // its barriers also fence the a2 reads above
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int n = (ntile0 + i) * 16 + 4 * g;
@@ -234,16 +260,18 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
     }
   }
   __syncthreads();
+  STAMP(19);
 
   // ---- out = FiLM3(LN(W2 SiLU(W1 SiLU(x3) + b1) + b2 + x3)); the 2*DM hidden layer is processed in two halves
   f32x4 acc2[NT][MT];
   acc_zero(acc2);
+#pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
     {
       f32x4 acc[NT][MT];
       acc_zero(acc);
       const int nt = hh * (DM / 16) + ntile0;
-      mainloop<T, MT, NT>(acc, reinterpret_cast<const T*>(p.w_f1) + ((size_t)nt * KC * 64 + lane) * 8,
+      mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_f1) + ((size_t)nt * KC * 64 + lane) * 8,
                           R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -259,10 +287,12 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
       }
     }
     __syncthreads();
+    STAMP(20 + 2 * hh);
     // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]
-    mainloop<T, MT, NT>(acc2, reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8,
+    mainloop<T, MT, NT, RING>(acc2, reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8,
                         R3 + (row0 + l15) * S + g * 8 * ES, S, KC, 1, 2 * KC);
     __syncthreads();   // R3 is rewritten by the next half
+    STAMP(21 + 2 * hh);
   }
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
     for (int j = 0; j < MT; ++j)
       acc2[i][j] += bi + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n);
   }
-  layernorm_rows<MT, NT, 4, BM>(acc2, red, wn, row0, lane, DM);
+  layernorm_rows<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM);
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int n = (ntile0 + i) * 16 + 4 * g;
@@ -283,22 +313,23 @@ __global__ __launch_bounds__(512) void enc_bc_kernel(const EncLayerParams p) {
       const int r = m0 + row0 + j * 16 + l15;
       const bool valid = r < p.Lk;
       const f32x4 v = acc2[i][j] * ga + be;
-      if (valid) store4(reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + r) * DM + n, v);
+      if (valid) store4(reinterpret_cast<T*>(p.out) + (unsigned)((b * p.Lk + r) * DM + n), v);
       if (p.pool) {
         f32x4 q;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = 0.5f * (v[k] + __shfl_xor(v[k], 1));
         if (valid && !(lane & 1))
-          store4(reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + (r >> 1)) * DM + n, q);
+          store4(reinterpret_cast<T*>(p.pool) + (unsigned)((b * (p.Lk / 2) + (r >> 1)) * DM + n), q);
       }
     }
   }
+  STAMP(24);
 }
 
 template <typename T, int DM>
 hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
   const int tiles = (p.Lk + BM - 1) / BM;
-  const size_t red = 2 * 4 * BM * sizeof(float);
+  const size_t red = 2 * 8 * BM * sizeof(float);
   if (which == 0) {
     const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red;
     hipLaunchKernelGGL((enc_a_kernel<T, DM>), dim3(p.B * tiles), dim3(512), lds, st, p);

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         const f32x4 bi = *reinterpret_cast<const f32x4*>(p.bias0 + n);
         f32x4 ga = (f32x4){1, 1, 1, 1}, be = (f32x4){0, 0, 0, 0};
         if (p.film_mode == 2) {
-          ga = *reinterpret_cast<const f32x4*>(p.gam + (size_t)b * p.film_bs + n);
-          be = *reinterpret_cast<const f32x4*>(p.bet + (size_t)b * p.film_bs + n);
+          ga = *reinterpret_cast<const f32x4*>(p.gam + (long)(b / p.film_div) * p.film_bs + n);
+          be = *reinterpret_cast<const f32x4*>(p.bet + (long)(b / p.film_div) * p.film_bs + n);
         }
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] + bi) * ga + be;
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int n = (ntile0 + i) * 16 + 4 * g;
     f32x4 ga = (f32x4){1, 1, 1, 1}, be = (f32x4){0, 0, 0, 0};
     if (p.film_mode == 1) {
-      ga = *reinterpret_cast<const f32x4*>(p.gam + (size_t)b * p.film_bs + n);
-      be = *reinterpret_cast<const f32x4*>(p.bet + (size_t)b * p.film_bs + n);
+      ga = *reinterpret_cast<const f32x4*>(p.gam + (long)(b / p.film_div) * p.film_bs + n);
+      be = *reinterpret_cast<const f32x4*>(p.bet + (long)(b / p.film_div) * p.film_bs + n);
     }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -353,7 +353,7 @@ void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
 }
 
 hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st) {
-  if (p.nseg < 1 || p.nseg > 2 || p.N % 16 || p.n_store % 16 || (p.pool && (p.L & 1))) return hipErrorInvalidValue;
+  if (p.film_div < 1 || p.nseg < 1 || p.nseg > 2 || p.N % 16 || p.n_store % 16 || (p.pool && (p.L & 1))) return hipErrorInvalidValue;
   for (int s = 0; s < p.nseg; ++s)
     if (p.seg[s].C % 32 || (p.seg[s].taps != 1 && p.seg[s].taps != 3)) return hipErrorInvalidValue;
   int bm, bn;

@@ -18,11 +18,11 @@ template <typename T> __host__ __device__ inline int tile_stride(int C) { return
 //           caller contract over a K-slice [kt0, kt0+KC) of a wider matrix (wbase advanced by kt0*512)
 // Weight fragments stream L2 -> VGPRs through a D-deep register ring; the body is branch-free and
 // statically indexed so hipcc emits counted s_waitcnt vmcnt((D-1)*NT) instead of draining the queue.
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, int RING = (sizeof(T) == 2 ? 24 : 12)>
 DHW_DEV void mainloop(f32x4 (&acc)[NT][MT], const T* __restrict__ wbase, const char* abase, int stride, int KC, int taps,
                       int KTS = 0) {
   constexpr int ES = sizeof(T);
-  constexpr int D0 = (ES == 2 ? 12 : 6) / NT;
+  constexpr int D0 = RING / NT;                     // ring depth: ~RING weight fragments (1 KiB each) in flight per wave
   constexpr int D = D0 < 2 ? 2 : (D0 > 8 ? 8 : D0);
   const int KT = KC * taps;
   if (KTS == 0) KTS = KT;

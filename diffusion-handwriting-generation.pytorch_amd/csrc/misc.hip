@@ -63,17 +63,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* text, int 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void film_apply_kernel(const T* in, int rows, int dim, const float* gam,
-                                                          const float* bet, long bs, T* out, long total4) {
+__global__ __launch_bounds__(256) void film_apply_kernel(const T* in, int in_B, int rows, int dim, const float* gam,
+                                                          const float* bet, long bs, int div, T* out, long total4) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const long e = i * 4;
   const long r = e / dim;
   const int c = (int)(e - r * dim);
   const long b = r / rows;
-  const f32x4 x = load4(in + e);
-  const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + b * bs + c);
-  const f32x4 be = *reinterpret_cast<const f32x4*>(bet + b * bs + c);
+  const f32x4 x = load4(in + ((b % in_B) * rows + (r - b * rows)) * dim + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + (b / div) * bs + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(bet + (b / div) * bs + c);
   store4(out + e, x * ga + be);
 }
 
@@ -213,13 +213,14 @@ hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float*
     hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, vocab, (float*)out);
   return hipGetLastError();
 }
-hipError_t launch_film_apply(int prec, const void* in, int B, int rows, int dim, const float* gam, const float* bet,
-                             long bs, void* out, hipStream_t st) {
+hipError_t launch_film_apply(int prec, const void* in, int in_B, int B, int rows, int dim, const float* gam,
+                             const float* bet, long bs, int div, void* out, hipStream_t st) {
   const long total4 = (long)B * rows * dim / 4;
+  if (div < 1 || in_B < 1) return hipErrorInvalidValue;
   if (prec == PREC_BF16)
-    hipLaunchKernelGGL(film_apply_kernel<bf16_t>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const bf16_t*)in, rows, dim, gam, bet, bs, (bf16_t*)out, total4);
+    hipLaunchKernelGGL(film_apply_kernel<bf16_t>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const bf16_t*)in, in_B, rows, dim, gam, bet, bs, div, (bf16_t*)out, total4);
   else
-    hipLaunchKernelGGL(film_apply_kernel<float>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const float*)in, rows, dim, gam, bet, bs, (float*)out, total4);
+    hipLaunchKernelGGL(film_apply_kernel<float>, dim3(nblk(total4, 256)), dim3(256), 0, st, (const float*)in, in_B, rows, dim, gam, bet, bs, div, (float*)out, total4);
   return hipGetLastError();
 }
 hipError_t launch_cast(int prec, const float* in, long n, void* out, hipStream_t st) {
