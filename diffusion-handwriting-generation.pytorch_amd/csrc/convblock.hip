@@ -2,24 +2,45 @@
 //
 //     out = FiLM3(fc(SiLU(FiLM2(conv2(SiLU(FiLM1(conv1(SiLU(x))))))))) + conv_skip(x)
 //
-// A workgroup owns BM-2 consecutive stroke rows of one sample.  x (raw and SiLU'd, +2 halo rows each
-// side) is staged into LDS once; conv1 -> h1 and conv2 -> h2 never leave LDS; the k=3 taps of every
-// conv read row-shifted views of the staged tiles; fc and conv_skip accumulate into the same MFMA
-// accumulators with the FiLM3 affine applied in between.  Weights stream from L2 in MFMA-fragment
-// order (gemm_core.h).  Replaces three launches and two HBM/L2 round trips of h1/h2.
+// A workgroup owns BM-2 consecutive stroke rows of one sample.  x (raw and SiLU'd, +2 halo rows each side) is
+// staged into LDS once — for enc1 it is computed on the fly from the (dx,dy) strokes (input Linear(2->C),
+// model.py:139), so the sampler state never round-trips through an activation buffer; conv1 -> h1 and
+// conv2 -> h2 never leave LDS; the k=3 taps of every conv read row-shifted views of the staged tiles; fc and
+// conv_skip accumulate into the same MFMA accumulators with the FiLM3 affine applied in between.  Weights
+// stream from L2 in MFMA-fragment order through a register ring that is re-filled for the NEXT stage before
+// the current stage's epilogue (gemm_core.h).  The output tile goes through LDS so global stores are whole
+// coalesced rows (+ the AvgPool1d side output).  Replaces three launches and the HBM/L2 round trips of h1/h2.
+//
+// bf16: 8 waves (2 per SIMD), BM = 64.  fp32 (parity mode): 4 waves, BM = 32 (LDS budget).
 #include "gemm_core.h"
 #include "dhw_kernels.h"
 
 namespace {
 
-template <typename T, int BM, int CO>
-__global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockParams p) {
-  constexpr int ES = sizeof(T);
+template <int NT>
+struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles, requested before the main loop
+  f32x4 bias[NT], gam[NT], bet[NT];
+  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+      gam[i] = g ? *reinterpret_cast<const f32x4*>(g + n0 + 16 * i) : (f32x4){1, 1, 1, 1};
+      bet[i] = be ? *reinterpret_cast<const f32x4*>(be + n0 + 16 * i) : (f32x4){0, 0, 0, 0};
+    }
+  }
+};
+
+template <typename T, int BM, int CO, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4 < 2 ? 2 : NW / 4)))
+void convblock_kernel(const ConvBlockParams p) {
+  constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr int BMO = BM - 2;            // output rows per workgroup
   constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
   constexpr int C1 = CO / 2;             // conv1 output channels
-  constexpr int MT1 = BM / 2 / 16, NT1 = C1 / 2 / 16;   // stage 1: waves 2 (rows) x 2 (channels)
-  constexpr int MT2 = BM / 16, NT2 = CO / 4 / 16;       // stages 2,3: waves 1 x 4
+  constexpr int WM1 = NW / 2, WM2 = NW / 4;                     // stage 1: waves WM1 x 2; stages 2,3: waves WM2 x 4
+  constexpr int MT1 = BM / WM1 / 16, NT1 = C1 / 2 / 16;
+  constexpr int MT2 = BM / WM2 / 16, NT2 = CO / 4 / 16;
+  constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3;   // fewer fragments in flight for the widest block (VGPR budget)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,19 +55,50 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockParams p)
   char* XR = XS + RX * SX;               // x         [RX][Cin]
   char* H1 = XR + RX * SX;               // h1        [BM+2][C1]  (index i <-> sample row m0-1+i)
   char* H2 = H1 + (BM + 2) * SH1;        // h2        [BM][CO]    (index i <-> sample row m0+i)
+  const float* gam = p.film + (size_t)b * p.film_bs;
+  const float* bet = gam + p.film_tot;
+
+  // wave coordinates of the two layouts
+  const int wm1 = wave >> 1, wn1 = wave & 1, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
+  const int wm2 = wave >> 2, wn2 = wave & 3, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
+  const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
+  const int KCin = Cin / 32;
+
+  WRing<T, NT1, RING> ring1;
+  Epi<NT1> ep1;
+  ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
+  ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
 
   // ---- stage 0: x tile -> LDS (raw + SiLU), zero outside the sample ('same' padding)
-  {
+  if (p.strokes) {
+    // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load
+    const int cpr = Cin / 4;   // 4 channels per item
+    for (int id = tid; id < RX * cpr; id += NTHR) {
+      const int r = id / cpr, c = (id - r * cpr) * 4;
+      const int lrow = m0 - 2 + r;
+      f32x4 v = (f32x4){0, 0, 0, 0}, sv = v;
+      if (lrow >= 0 && lrow < p.L) {
+        const float s0 = p.strokes[(size_t)(b * p.L + lrow) * 2], s1 = p.strokes[(size_t)(b * p.L + lrow) * 2 + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = to_f(from_f<T>(p.in_w[(c + k) * 2] * s0 + p.in_w[(c + k) * 2 + 1] * s1 + p.in_b[c + k]));
+          sv[k] = silu_f(v[k]);
+        }
+      }
+      store4(reinterpret_cast<T*>(XR + r * SX) + c, v);
+      store4(reinterpret_cast<T*>(XS + r * SX) + c, sv);
+    }
+  } else {
     const int cpr = Cin * ES / 16;
     const int total = RX * cpr;
     const char* src = reinterpret_cast<const char*>(p.x);
     constexpr int U = 4;
-    for (int base = tid; base < total; base += 256 * U) {
+    for (int base = tid; base < total; base += NTHR * U) {
       uint4 v[U];
       int dst[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int id = base + u * 256;
+        const int id = base + u * NTHR;
         const int r = id / cpr, cc = id - r * cpr;
         const int lrow = m0 - 2 + r;
         v[u] = make_uint4(0, 0, 0, 0);
@@ -64,135 +116,110 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockParams p)
         *reinterpret_cast<uint4*>(XS + dst[u]) = v[u];
       }
     }
-    // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
-    for (int id = tid; id < 2 * SH1 / 16; id += 256)
-      *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();
+  // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
+  for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
+    *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
+  lds_barrier();
 
-  const float* gam = p.film + (size_t)b * p.film_bs;
-  const float* bet = gam + p.film_tot;
+  WRing<T, NT2, RING> ring2;
+  Epi<NT2> ep2;
 
   // ---- stage 1: h1 = SiLU(FiLM1(conv1(SiLU(x)))) for sample rows [m0-1, m0-1+BM)
   {
-    const int wm = wave >> 1, wn = wave & 1;
-    const int row0 = wm * (BM / 2), ntile0 = wn * NT1;
     f32x4 acc[NT1][MT1];
     acc_zero(acc);
-    const int KC = Cin / 32;
-    const T* wbase = reinterpret_cast<const T*>(p.w_c1) + ((size_t)ntile0 * KC * 3 * 64 + lane) * 8;
-    mainloop<T, MT1, NT1>(acc, wbase, XS + (row0 + l15) * SX + g * 8 * ES, SX, KC, 3);
+    ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+    ring2.fill(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8, (C1 / 32) * 3);
+    ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
 #pragma unroll
-    for (int i = 0; i < NT1; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_c1 + n);
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f1 + n);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f1 + n);
+    for (int i = 0; i < NT1; ++i)
 #pragma unroll
       for (int j = 0; j < MT1; ++j) {
-        const int r = row0 + j * 16 + l15;
+        const int r = row01 + j * 16 + l15;
         const int srow = m0 - 1 + r;
-        f32x4 v = (acc[i][j] + bi) * ga + be;
+        f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_f(v[k]) : 0.f;   // conv2 pads h1 with zeros
-        store4(reinterpret_cast<T*>(H1 + r * SH1) + n, v);
+        store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
       }
-    }
   }
-  __syncthreads();
+  lds_barrier();
 
-  const int ntile0 = wave * NT2;
   // ---- stage 2: h2 = SiLU(FiLM2(conv2(h1))) for sample rows [m0, m0+BM) (the last 2 are discarded)
   {
     f32x4 acc[NT2][MT2];
     acc_zero(acc);
-    const int KC = C1 / 32;
-    const T* wbase = reinterpret_cast<const T*>(p.w_c2) + ((size_t)ntile0 * KC * 3 * 64 + lane) * 8;
-    mainloop<T, MT2, NT2>(acc, wbase, H1 + l15 * SH1 + g * 8 * ES, SH1, KC, 3);
+    ring2.template run<MT2>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
+    ring2.fill(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * (CO / 32) * 64 + lane) * 8, CO / 32);
 #pragma unroll
-    for (int i = 0; i < NT2; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_c2 + n);
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f2 + n);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f2 + n);
+    for (int i = 0; i < NT2; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j) {
-        f32x4 v = (acc[i][j] + bi) * ga + be;
+        f32x4 v = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
-        store4(reinterpret_cast<T*>(H2 + (j * 16 + l15) * SH2) + n, v);
+        store4(reinterpret_cast<T*>(H2 + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, v);
       }
-    }
+    ep2.load(p.b_fc, gam + p.f3, bet + p.f3, n2);
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- stage 3: out = FiLM3(fc(h2)) + conv_skip(x)
-  {
-    f32x4 acc[NT2][MT2];
-    acc_zero(acc);
-    {
-      const int KC = CO / 32;
-      const T* wbase = reinterpret_cast<const T*>(p.w_fc) + ((size_t)ntile0 * KC * 64 + lane) * 8;
-      mainloop<T, MT2, NT2>(acc, wbase, H2 + l15 * SH2 + g * 8 * ES, SH2, KC, 1);
-    }
+  f32x4 acc[NT2][MT2];
+  acc_zero(acc);
+  ring2.template run<MT2>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
+  ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
 #pragma unroll
-    for (int i = 0; i < NT2; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_fc + n);
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f3 + n);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f3 + n);
+  for (int i = 0; i < NT2; ++i)
 #pragma unroll
-      for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + bi) * ga + be;
-    }
-    {
-      const int KC = Cin / 32;
-      const T* wbase = reinterpret_cast<const T*>(p.w_skip) + ((size_t)ntile0 * KC * 3 * 64 + lane) * 8;
-      mainloop<T, MT2, NT2>(acc, wbase, XR + (l15 + 1) * SX + g * 8 * ES, SX, KC, 3);   // out row i <- x rows i+1+tap
-    }
+    for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
+  ep2.load(p.b_skip, nullptr, nullptr, n2);
+  ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+  lds_barrier();   // every wave is done with the operand tiles: reuse LDS for the output tile
+
+  const int rows_valid = min(BMO, p.L - m0);
+  if (p.out_f32) {
+    constexpr int SO = CO * 4 + 16;
 #pragma unroll
-    for (int i = 0; i < NT2; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_skip + n);
+    for (int i = 0; i < NT2; ++i)
 #pragma unroll
-      for (int j = 0; j < MT2; ++j) {
-        const int r = j * 16 + l15;
-        const int srow = m0 + r;
-        const bool valid = r < BMO && srow < p.L;
-        const f32x4 v = acc[i][j] + bi;
-        if (valid) {
-          const size_t o = (size_t)(b * p.L + srow) * CO + n;
-          if (p.out_f32) store4(reinterpret_cast<float*>(p.out) + o, v);
-          else store4(reinterpret_cast<T*>(p.out) + o, v);
-        }
-        if (p.pool) {   // AvgPool1d(2) side output (model.py:93): rows 2i, 2i+1 are lanes l, l^1
-          f32x4 q;
+      for (int j = 0; j < MT2; ++j)
+        store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+    lds_barrier();
+    tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
+  } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) q[k] = 0.5f * (v[k] + __shfl_xor(v[k], 1));
-          if (valid && !(lane & 1))
-            store4(reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + (srow >> 1)) * CO + n, q);
-        }
-      }
-    }
+    for (int i = 0; i < NT2; ++i)
+#pragma unroll
+      for (int j = 0; j < MT2; ++j)
+        store4(reinterpret_cast<T*>(smem + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+    lds_barrier();
+    tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
+    if (p.pool)   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
+      tile_copy_out_pool<T>(smem, SH2, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * CO, CO, rows_valid, CO, tid, NTHR);
   }
 }
 
 template <typename T, int BM, int CO>
 size_t lds_bytes(int Cin) {
-  return (size_t)2 * (BM + 2) * tile_stride<T>(Cin) + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * tile_stride<T>(CO);
+  const size_t ops = (size_t)2 * (BM + 2) * tile_stride<T>(Cin) + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * tile_stride<T>(CO);
+  const size_t outf = (size_t)BM * (CO * 4 + 16);
+  return ops > outf ? ops : outf;
 }
 
-template <typename T, int BM, int CO>
+template <typename T, int BM, int CO, int NW>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st) {
   const size_t lds = lds_bytes<T, BM, CO>(p.Cin);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO>), dim3(p.B * tiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO>
+template <typename T, int BM, int CO, int NW>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -200,27 +227,27 @@ hipError_t attr() {
 
 hipError_t convblock_init() {
   hipError_t e;
-  if ((e = attr<bf16_t, 64, 128>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 256>()) != hipSuccess) return e;
-  if ((e = attr<float, 32, 128>()) != hipSuccess) return e;
-  if ((e = attr<float, 32, 192>()) != hipSuccess) return e;
-  return attr<float, 32, 256>();
+  if ((e = attr<bf16_t, 64, 128, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
+  if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
+  if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
+  return attr<float, 32, 256, 4>();
 }
 
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) {
-  if (p.Cin % 32 || (p.L & 1)) return hipErrorInvalidValue;
+  if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32)) return hipErrorInvalidValue;
   if (prec == PREC_BF16) {
     switch (p.Cout) {
-      case 128: return launch_t<bf16_t, 64, 128>(p, st);
-      case 192: return launch_t<bf16_t, 64, 192>(p, st);
-      case 256: return launch_t<bf16_t, 64, 256>(p, st);
+      case 128: return launch_t<bf16_t, 64, 128, 8>(p, st);
+      case 192: return launch_t<bf16_t, 64, 192, 8>(p, st);
+      case 256: return launch_t<bf16_t, 64, 256, 8>(p, st);
     }
   } else {
     switch (p.Cout) {
-      case 128: return launch_t<float, 32, 128>(p, st);
-      case 192: return launch_t<float, 32, 192>(p, st);
-      case 256: return launch_t<float, 32, 256>(p, st);
+      case 128: return launch_t<float, 32, 128, 4>(p, st);
+      case 192: return launch_t<float, 32, 192, 4>(p, st);
+      case 256: return launch_t<float, 32, 256, 4>(p, st);
     }
   }
   return hipErrorInvalidValue;

@@ -512,6 +512,7 @@ struct Ctx {
   int film_div = 1;    // samples per FiLM row
   int in_B = 0;        // batch of the sigma-independent inputs (0 = B); the text plane replicates them over steps
   std::string sfx;     // suffix of the text-side output buffers: "" (per call) or ".T" (all-steps plane)
+  bool fuse_input = false;  // enc1 evaluates input_dense while staging (sampling loop); forward() keeps the tap
   bool use_plane = false;   // stroke path reads the text K/V of step `plane_step` from the plane
   long plane_step = 0;
 };
@@ -576,10 +577,11 @@ void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, 
 
 // cnn.py:64-87 as three fused GEMM launches
 void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
-                void* pool) {
+                void* pool, const float* strokes = nullptr) {
   dhw_handle* h = c.h;
   if (h->fuse) {
     ConvBlockParams q{};
+    q.strokes = strokes; q.in_w = h->in_w; q.in_b = h->in_b;
     q.x = x; q.B = c.B; q.L = L; q.Cin = w.cin; q.Cout = w.cout;
     q.w_c1 = w.w_c1; q.w_c2 = w.w_c2; q.w_fc = w.w_fc; q.w_skip = w.w_skip;
     q.b_c1 = w.b_c1; q.b_c2 = w.b_c2; q.b_fc = w.b_fc; q.b_skip = w.b_skip;
@@ -880,9 +882,12 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   dhw_handle* h = c.h;
   const dhw_dims& d = h->dims;
   const int L = c.L, dt = 2 * d.c2;
-  RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(c, "x0"), c.st));
-  tap(c, "input_dense", "x0", L, d.c1);
-  conv_block(c, "enc1", h->enc1, BUF(c, "x0"), L, BUF(c, "enc1"), false, BUF(c, "enc1.pool"));
+  const bool fin = c.fuse_input && h->fuse;
+  if (!fin) {
+    RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(c, "x0"), c.st));
+    tap(c, "input_dense", "x0", L, d.c1);
+  }
+  conv_block(c, "enc1", h->enc1, BUF(c, "x0"), L, BUF(c, "enc1"), false, BUF(c, "enc1.pool"), fin ? strokes : nullptr);
   conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr);
   enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"));
   conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr);
@@ -1191,6 +1196,7 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
   out += (size_t)b0 * L * 3;
   if (noise) noise += (size_t)b0 * L * 2;
   Ctx c{h, w, st, Bs, L, Lt, h->dims.S * 5, h->d_film_T, 0};
+  c.fuse_input = true;
   // x_T
   if (noise) {
     hipError_t e = hipMemcpyAsync(w->d_xt, noise, rows * 2 * 4, hipMemcpyDeviceToDevice, st);

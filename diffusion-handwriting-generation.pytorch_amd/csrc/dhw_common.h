@@ -95,6 +95,12 @@ DHW_DEV void store4(bf16_t* p, const f32x4& v) {
 }
 DHW_DEV void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue
+// (s_waitcnt vmcnt(0)), which would stall every wave until the NEXT stage's prefetched weight fragments have
+// landed; the fused kernels exchange data between waves through LDS only, so lgkmcnt(0) + s_barrier suffices
+// (cdna_hip_programming.md §5 "Pipelining across barriers").
+DHW_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 DHW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 DHW_DEV float to_f(bf16_t x) { return (float)x; }
 DHW_DEV float to_f(float x) { return x; }

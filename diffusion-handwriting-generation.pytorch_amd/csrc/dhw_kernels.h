@@ -51,6 +51,8 @@ void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN);
 // ---------------------------------------------------------------- fused ConvBlock (cnn.py:64-87), one launch
 struct ConvBlockParams {
   const void* x;                      // block input [B*L, Cin]
+  const float* strokes;               // enc1 only (or null): x = in_w·strokes + in_b is evaluated while staging (model.py:139)
+  const float *in_w, *in_b;           // input_dense weight [Cin,2], bias [Cin]
   int B, L, Cin, Cout;
   const void *w_c1, *w_c2, *w_fc, *w_skip;     // packed as for the GEMM kernel
   const float *b_c1, *b_c2, *b_fc, *b_skip;

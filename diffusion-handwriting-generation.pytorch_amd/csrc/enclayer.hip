@@ -12,11 +12,11 @@
 // (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
 #include "attn_core.h"
 #include "gemm_core.h"
+#include <cstdlib>
 #include "dhw_kernels.h"
 
 namespace {
 
-constexpr int BM = 64;
 
 // diagnostic stage stamps (100 MHz s_memrealtime), only when the caller passes a buffer
 #define STAMP(slot)                                                                                   \
@@ -24,7 +24,7 @@ constexpr int BM = 64;
     if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
-template <typename T>
+template <typename T, int BM>
 DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
   constexpr int ES = sizeof(T);
   const int cpr = C * ES / 16;
@@ -48,12 +48,26 @@ DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int
   }
 }
 
-template <typename T, int DM>
+// epilogue parameters of one stage (this lane's 4 channels of each of its NT channel tiles), requested BEFORE the
+// stage's main loop so their L2 latency is hidden behind it
+template <int NT>
+struct EpiParams {
+  f32x4 bias[NT], gam[NT], bet[NT];
+  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {   // n0: first channel of this lane
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+      gam[i] = g ? *reinterpret_cast<const f32x4*>(g + n0 + 16 * i) : (f32x4){1, 1, 1, 1};
+      bet[i] = be ? *reinterpret_cast<const f32x4*>(be + n0 + 16 * i) : (f32x4){0, 0, 0, 0};
+    }
+  }
+};
+
+template <typename T, int DM, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  constexpr int RING = 24;   // weight fragments in flight per wave (register budget: 256 at 2 waves/SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -67,83 +81,92 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
   const int row0 = wm * (BM / WM), ntile0 = wn * NT;
+  const int n0 = ntile0 * 16 + 4 * g;                          // this lane's first channel
+  const size_t wlane = ((size_t)ntile0 * KC * 64 + lane) * 8;  // this wave/lane's offset into a packed [DM x DM] block
+  const char* xop = XR + (row0 + l15) * S + g * 8 * ES;
+  const char* qop = QR + (row0 + l15) * S + g * 8 * ES;
 
+  WRing<T, NT> ring;
+  EpiParams<NT> ep;
   STAMP(0);
-  stage_rows<T>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
-  __syncthreads();
+  ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
+  ep.load(p.b_q1, nullptr, nullptr, n0);
+  stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
+  lds_barrier();
   STAMP(1);
 
   {  // ---- q1 = Wq x + b + PE·Wq[row]
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_q1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
-                        XR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+    f32x4 pb[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_q1 + n);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r = row0 + j * 16 + l15;
-        const f32x4 v = acc[i][j] + bi + *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + r) * DM + n));
-        store4(reinterpret_cast<T*>(QR + r * S) + n, v);
-      }
-    }
+      for (int j = 0; j < MT; ++j)
+        pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + row0 + j * 16 + l15) * DM + n0 + 16 * i));
+    ring.template run<MT>(acc, xop, S, KC);
+    STAMP(8);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc[i][j] + ep.bias[i] + pb[i][j]);
+    STAMP(9);
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(2);
 
   {  // ---- cross attention over the Lt text keys; a1 overwrites q1 in place (same wave, same rows/columns)
-    const int rg = wave & 3, hs = wave >> 2;
+    constexpr int RG = BM / 16, HS = 8 / RG;   // waves: RG row groups x HS head sets
+    const int rg = wave % RG, hs = wave / RG;
     const T* k1 = reinterpret_cast<const T*>(p.k1);
     const T* vt1 = reinterpret_cast<const T*>(p.vt1);
 #pragma unroll 1
-    for (int h = hs; h < H; h += 2) {
+    for (int h = hs; h < H; h += HS) {
       Frag<T> qf[2];
       const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + h * 64 + 8 * g;
       qf[0] = frag_load(qrow);
       qf[1] = frag_load(qrow + 32);
       f32x4 o[4];
       attn_wave16_auto<T, 64>(qf, k1 + (size_t)(b * p.Lt + l15) * DM + h * 64, DM,
-                         vt1 + ((size_t)b * DM + h * 64 + l15) * p.lpadT + 4 * g, p.lpadT,
-                         p.text ? p.text + (size_t)b * p.Lt : nullptr, p.Lt, o);
+                              vt1 + ((size_t)b * DM + h * 64 + l15) * p.lpadT + 4 * g, p.lpadT,
+                              p.text ? p.text + (size_t)b * p.Lt : nullptr, p.Lt, o);
       T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
 #pragma unroll
       for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
     }
   }
-  __syncthreads();
+  ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
+  ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
+  lds_barrier();
   STAMP(3);
 
   {  // ---- x2 = FiLM1(LN(Wd a1 + b)) + x
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_d1) + ((size_t)ntile0 * KC * 64 + lane) * 8,
-                        QR + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+    ring.template run<MT>(acc, qop, S, KC);
+    STAMP(10);
+    ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + wlane, KC);   // q2 chunk: flies during the LayerNorm epilogue
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_d1 + (ntile0 + i) * 16 + 4 * g);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] += bi;
-    }
+      for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
     layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);
+    STAMP(11);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f1 + n);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f1 + n);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int r = row0 + j * 16 + l15;
-        T* xp = reinterpret_cast<T*>(XR + r * S) + n;
-        const f32x4 v = acc[i][j] * ga + be + load4(xp);
+        T* xp = reinterpret_cast<T*>(XR + r * S) + n0 + 16 * i;
+        const f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(xp);
         store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
-        if (m0 + r < p.Lk) store4(reinterpret_cast<T*>(p.x2) + (unsigned)((b * p.Lk + m0 + r) * DM + n), v);
       }
-    }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(4);
+  const int rows_valid = min(BM, p.Lk - m0);
+  tile_copy_out<T>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
 
   // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
   // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
@@ -153,40 +176,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(opaque));
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    const int nt = chunk * (DM / 16) + ntile0;
-    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_qkv2) + ((size_t)nt * KC * 64 + lane) * 8,
-                              XR + (row0 + l15) * S + g * 8 * ES + opaque, S, KC, 1);
+    ep.load(p.b_qkv2 + chunk * DM, nullptr, nullptr, n0 + opaque);
+    f32x4 pb[NT][MT];
+    if (chunk < 2) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int nl = (ntile0 + i) * 16 + 4 * g + opaque;       // column inside the chunk
-      const int n = chunk * DM + nl;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_qkv2 + n);
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r = m0 + row0 + j * 16 + l15;
-        f32x4 v = acc[i][j] + bi;
-        if (chunk < 2) {
-          if (r < p.Lk) {
-            v += *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)(r * 2 * DM + n));
-            store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + r) * 2 * DM + n), v);
-          }
-        } else if (r < p.lpadX) {   // V: key-contiguous for the PV product; rows past Lk stay zero
-          const unsigned vo = (unsigned)((b * DM + nl) * p.lpadX + r);
+        for (int j = 0; j < MT; ++j)
+          pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
+    }
+    ring.template run<MT>(acc, xop + opaque, S, KC);
+    STAMP(12 + chunk);
+    if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
+    lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V) is free: every wave is past its readers
+    if (chunk < 2) {
+      // q2 / k2 chunk -> LDS tile [row][DM] -> coalesced rows of qk2 [.., 2*DM]
 #pragma unroll
-          for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(p.vt2)[vo + (unsigned)(k * p.lpadX)] = from_f<T>(r < p.Lk ? v[k] : 0.f);
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i + opaque, acc[i][j] + ep.bias[i] + pb[i][j]);
+      lds_barrier();
+      tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * 2 * DM + chunk * DM, 2 * DM, rows_valid, DM, tid, 512);
+    } else {
+      // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past Lk) -> coalesced 128-byte rows of vt2
+      constexpr int SV = BM * ES + 16;
+      char* VT = smem;   // spans the x2 and q1 regions: DM * SV <= 2 * BM * S
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const int rl = row0 + j * 16 + l15;
+          const f32x4 v = acc[i][j] + ep.bias[i];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<T*>(VT + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(m0 + rl < p.Lk ? v[k] : 0.f);
         }
+      lds_barrier();
+      constexpr int EPV = 16 / ES, PPR = BM / EPV;   // 16-byte pieces per channel row
+      for (int id = tid; id < DM * PPR; id += 512) {
+        const int ch = id / PPR, part = id - ch * PPR;
+        if (m0 + (part + 1) * EPV <= p.lpadX)
+          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + ch) * p.lpadX + m0 + part * EPV) =
+              *reinterpret_cast<const uint4*>(VT + ch * SV + part * 16);
       }
     }
     STAMP(5 + chunk);
   }
 }
 
-template <typename T, int DM>
+template <typename T, int DM, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p) {
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  constexpr int RING = DM == 384 ? 18 : 24;   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
+  constexpr int RING = DM == 384 ? 15 : 24;   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -201,14 +245,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
   const int row0 = wm * (BM / WM), ntile0 = wn * NT;
+  const int n0 = ntile0 * 16 + 4 * g;
+  const size_t wlane = ((size_t)ntile0 * KC * 64 + lane) * 8;
+  const char* op1 = R1 + (row0 + l15) * S + g * 8 * ES;
+  const char* op3 = R3 + (row0 + l15) * S + g * 8 * ES;
 
+  WRing<T, NT, RING> ring;
+  EpiParams<NT> ep;
   STAMP(16);
   {  // ---- self attention: q2, k2 from qk2, v2 from vt2 (all rows of the sample) -> a2 in LDS
-    const int rg = wave & 3, hs = wave >> 2;
+    constexpr int RG = BM / 16, HS = 8 / RG;   // waves: RG row groups x HS head sets
+    const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
     const T* vt2 = reinterpret_cast<const T*>(p.vt2);
 #pragma unroll 1
-    for (int h = hs; h < H; h += 2) {
+    for (int h = hs; h < H; h += HS) {
       if (p.dbg & 1) break;
       Frag<T> qf[2];
       const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + h * 64 + 8 * g;
@@ -216,50 +267,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       qf[1] = frag_load(qrow + 32);
       f32x4 o[4];
       attn_wave16_auto<T, 64>(qf, qk + (size_t)(b * p.Lk + l15) * 2 * DM + DM + h * 64, 2 * DM,
-                         vt2 + ((size_t)b * DM + h * 64 + l15) * p.lpadX + 4 * g, p.lpadX, nullptr, p.Lk, o);
+                              vt2 + ((size_t)b * DM + h * 64 + l15) * p.lpadX + 4 * g, p.lpadX, nullptr, p.Lk, o);
       T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
 #pragma unroll
       for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
     }
   }
-  __syncthreads();
+  ring.fill(reinterpret_cast<const T*>(p.w_d2) + wlane, KC);   // in flight across the barrier
+  ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
+  lds_barrier();
   STAMP(17);
 
   {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_d2) + ((size_t)ntile0 * KC * 64 + lane) * 8,
-                        R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+    f32x4 res[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_d2 + n);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int r = m0 + row0 + j * 16 + l15;
-        acc[i][j] += bi;
-        if (r < p.Lk) acc[i][j] += load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n));
+        res[i][j] = r < p.Lk ? load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i))
+                             : (f32x4){0, 0, 0, 0};
       }
-    }
+    ring.template run<MT>(acc, op1, S, KC);
+    ring.fill(reinterpret_cast<const T*>(p.w_f1) + wlane, KC);   // FFN half 0: flies during the LayerNorm epilogue
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
     STAMP(18);
     layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);   // its barriers also fence the a2 reads above
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = (ntile0 + i) * 16 + 4 * g;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f2 + n);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f2 + n);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int r = row0 + j * 16 + l15;
-        f32x4 v = acc[i][j] * ga + be;
-        store4(reinterpret_cast<T*>(R2 + r * S) + n, v);
+        f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
+        store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
-        store4(reinterpret_cast<T*>(R1 + r * S) + n, v);
+        store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
       }
-    }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(19);
 
   // ---- out = FiLM3(LN(W2 SiLU(W1 SiLU(x3) + b1) + b2 + x3)); the 2*DM hidden layer is processed in two halves
@@ -270,92 +321,90 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       f32x4 acc[NT][MT];
       acc_zero(acc);
-      const int nt = hh * (DM / 16) + ntile0;
-      mainloop<T, MT, NT, RING>(acc, reinterpret_cast<const T*>(p.w_f1) + ((size_t)nt * KC * 64 + lane) * 8,
-                          R1 + (row0 + l15) * S + g * 8 * ES, S, KC, 1);
+      ep.load(p.b_f1 + hh * DM, nullptr, nullptr, n0);
+      ring.template run<MT>(acc, op1, S, KC);
+      // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
+      ring.fill(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, KC, 2 * KC);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int nl = (ntile0 + i) * 16 + 4 * g;
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_f1 + hh * DM + nl);
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          f32x4 v = acc[i][j] + bi;
+          f32x4 v = acc[i][j] + ep.bias[i];
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
-          store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + nl, v);
+          store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v);
         }
-      }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(20 + 2 * hh);
-    // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]
-    mainloop<T, MT, NT, RING>(acc2, reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8,
-                        R3 + (row0 + l15) * S + g * 8 * ES, S, KC, 1, 2 * KC);
-    __syncthreads();   // R3 is rewritten by the next half
+    ring.template run<MT>(acc2, op3, S, KC);
+    if (hh == 0) ring.fill(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane, KC);   // FFN half 1
+    lds_barrier();   // R3 is rewritten by the next half
     STAMP(21 + 2 * hh);
   }
+  ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int n = (ntile0 + i) * 16 + 4 * g;
-    const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b_f2 + n);
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j)
-      acc2[i][j] += bi + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n);
-  }
+      acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
   layernorm_rows<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM);
+  // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int n = (ntile0 + i) * 16 + 4 * g;
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + p.f3 + n);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(bet + p.f3 + n);
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int r = m0 + row0 + j * 16 + l15;
-      const bool valid = r < p.Lk;
-      const f32x4 v = acc2[i][j] * ga + be;
-      if (valid) store4(reinterpret_cast<T*>(p.out) + (unsigned)((b * p.Lk + r) * DM + n), v);
-      if (p.pool) {
-        f32x4 q;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = 0.5f * (v[k] + __shfl_xor(v[k], 1));
-        if (valid && !(lane & 1))
-          store4(reinterpret_cast<T*>(p.pool) + (unsigned)((b * (p.Lk / 2) + (r >> 1)) * DM + n), q);
-      }
-    }
-  }
+    for (int j = 0; j < MT; ++j)
+      store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc2[i][j] * ep.gam[i] + ep.bet[i]);
+  lds_barrier();
+  const int rows_valid = min(BM, p.Lk - m0);
+  tile_copy_out<T>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
+  if (p.pool)
+    tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);
 }
 
-template <typename T, int DM>
+template <typename T, int DM, int BM>
 hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
   const int tiles = (p.Lk + BM - 1) / BM;
   const size_t red = 2 * 8 * BM * sizeof(float);
   if (which == 0) {
     const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red;
-    hipLaunchKernelGGL((enc_a_kernel<T, DM>), dim3(p.B * tiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   } else {
     const size_t lds = (size_t)3 * BM * tile_stride<T>(DM) + red;
-    hipLaunchKernelGGL((enc_bc_kernel<T, DM>), dim3(p.B * tiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((enc_bc_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   }
   return hipGetLastError();
 }
 
-template <typename T, int DM>
+template <typename T, int DM, int BM>
 hipError_t attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM, BM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bc_kernel<T, DM>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bc_kernel<T, DM, BM>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// 64-row tiles when that still gives every CU a workgroup, else 32-row tiles (twice the workgroups)
+template <typename T, int DM>
+hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st) {
+  const char* e = getenv("DHW_ENC_BM");
+  const int force = e ? atoi(e) : 0;
+  const bool small = force ? force == 32 : (long)p.B * ((p.Lk + 63) / 64) < 256;
+  return small ? launch_pair<T, DM, 32>(p, which, st) : launch_pair<T, DM, 64>(p, which, st);
 }
 
 }  // namespace
 
 hipError_t enclayer_init() {
   hipError_t e;
-  if ((e = attr<bf16_t, 192>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 256>()) != hipSuccess) return e;
-  return attr<bf16_t, 384>();
+  if ((e = attr<bf16_t, 192, 64>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 256, 64>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 384, 64>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 192, 32>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 256, 32>()) != hipSuccess) return e;
+  return attr<bf16_t, 384, 32>();
 }
 
 bool enclayer_supported(int prec, int d, int heads) {
@@ -366,9 +415,9 @@ bool enclayer_supported(int prec, int d, int heads) {
 hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st) {
   if (!enclayer_supported(prec, p.d, p.heads) || (p.pool && (p.Lk & 1))) return hipErrorInvalidValue;
   switch (p.d) {
-    case 192: return launch_pair<bf16_t, 192>(p, which, st);
-    case 256: return launch_pair<bf16_t, 256>(p, which, st);
-    case 384: return launch_pair<bf16_t, 384>(p, which, st);
+    case 192: return launch_bm<bf16_t, 192>(p, which, st);
+    case 256: return launch_bm<bf16_t, 256>(p, which, st);
+    case 384: return launch_bm<bf16_t, 384>(p, which, st);
   }
   return hipErrorInvalidValue;
 }

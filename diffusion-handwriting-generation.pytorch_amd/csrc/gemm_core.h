@@ -8,56 +8,117 @@
 // 16-lane fragment reads (row = lane&15, 16-byte column slot = lane>>4) spread over the banks.
 template <typename T> __host__ __device__ inline int tile_stride(int C) { return C * (int)sizeof(T) + 16; }
 
-// acc[i][j] += W(16 x 32*KT, channel tile i) * Act^T(32*KT x 16, row tile j)
-//   wbase : packed weights of this wave's first channel tile, already offset by lane*8 elements;
-//           fragment (i, kt) sits at wbase + (i*KT + kt)*512
-//   abase : LDS address of (this wave's first row + lane&15, element (lane>>4)*8) of the activation
-//           tile, including any row offset; tap t reads `stride` bytes further per tap
-//   KC    : k-chunks (of 32 channels) per tap;  taps: 1 or 3
-//   KTS   : fragment stride between consecutive channel tiles of the packed matrix (0 = KC*taps); lets a
-//           caller contract over a K-slice [kt0, kt0+KC) of a wider matrix (wbase advanced by kt0*512)
-// Weight fragments stream L2 -> VGPRs through a D-deep register ring; the body is branch-free and
-// statically indexed so hipcc emits counted s_waitcnt vmcnt((D-1)*NT) instead of draining the queue.
-template <typename T, int MT, int NT, int RING = (sizeof(T) == 2 ? 24 : 12)>
+DHW_DEV void keep_alive(const Frag<bf16_t>& f) { asm volatile("" ::"v"(f.v)); }
+DHW_DEV void keep_alive(const Frag<float>& f) { asm volatile("" ::"v"(f.lo), "v"(f.hi)); }
+
+// The weight stream of one GEMM stage: a D-deep ring of NT fragments per k-chunk, in registers.  fill() only
+// ISSUES the first D k-chunks' loads, so a caller can start the NEXT stage's weight stream before it runs the
+// current stage's epilogue / barrier (the loads fly during the epilogue); run() consumes the ring.
+// ABL (diagnostic builds only, tools/bench_stage.cpp): bit0 = no MFMA, bit1 = no weight re-loads, bit2 = no LDS reads
+template <typename T, int NT, int RING = (sizeof(T) == 2 ? 24 : 12)>
+struct WRing {
+  static constexpr int D0 = RING / NT;
+  static constexpr int D = D0 < 2 ? 2 : (D0 > 8 ? 8 : D0);   // ~RING fragments (1 KiB each for bf16) in flight per wave
+  Frag<T> q[D][NT];
+  const T* base;
+  int KT, KTS;
+
+  // wbase: packed weights of this wave's first channel tile, offset by lane*8 elements; KT k-chunks to contract;
+  // KTS: fragment stride between channel tiles of the packed matrix (0 = KT).
+  DHW_DEV void fill(const T* __restrict__ wbase, int kt, int kts = 0) {
+    base = wbase;
+    KT = kt;
+    KTS = kts ? kts : kt;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int k = d < KT ? d : KT - 1;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) q[d][i] = frag_load(base + ((size_t)i * KTS + k) * 512);
+    }
+  }
+
+  // acc[i][j] += W(channel tile i) * Act^T(row tile j) over the ring's KT k-chunks.
+  //   abase : LDS address of (this wave's first row + lane&15, element (lane>>4)*8) incl. any row offset;
+  //   stride: LDS row stride in bytes (tap t reads t rows further);  KC: k-chunks per tap (KT = KC * taps).
+  // The body is branch-free and statically indexed so hipcc emits counted s_waitcnt vmcnt((D-1)*NT).
+  template <int MT, int ABL = 0>
+  DHW_DEV void run(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
+    constexpr int ES = sizeof(T);
+    int aoff = 0, kc = 0;
+    const int tap_step = stride - (KC - 1) * 32 * ES;
+    auto step = [&](int d, int knext) {
+      Frag<T> a[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        if constexpr (ABL & 4) a[j] = frag_zero<T>();
+        else a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          if constexpr (ABL & 1) { keep_alive(q[d][i]); keep_alive(a[j]); }
+          else mma32(acc[i][j], q[d][i], a[j]);
+        }
+      const int kn = knext < KT ? knext : KT - 1;   // clamped: the last D re-loads are harmless
+      if constexpr (!(ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) q[d][i] = frag_load(base + ((size_t)i * KTS + kn) * 512);
+      }
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+    int kt = 0;
+    for (; kt + D <= KT; kt += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) step(d, kt + d + D);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (kt + d < KT) step(d, KT - 1);
+  }
+};
+
+// one-shot form: fill + run
+template <typename T, int MT, int NT, int RING = (sizeof(T) == 2 ? 24 : 12), int ABL = 0>
 DHW_DEV void mainloop(f32x4 (&acc)[NT][MT], const T* __restrict__ wbase, const char* abase, int stride, int KC, int taps,
                       int KTS = 0) {
-  constexpr int ES = sizeof(T);
-  constexpr int D0 = RING / NT;                     // ring depth: ~RING weight fragments (1 KiB each) in flight per wave
-  constexpr int D = D0 < 2 ? 2 : (D0 > 8 ? 8 : D0);
-  const int KT = KC * taps;
-  if (KTS == 0) KTS = KT;
-  Frag<T> wq[D][NT];
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const int k = d < KT ? d : KT - 1;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) wq[d][i] = frag_load(wbase + ((size_t)i * KTS + k) * 512);
+  WRing<T, NT, RING> ring;
+  ring.fill(wbase, KC * taps, KTS);
+  ring.template run<MT, ABL>(acc, abase, stride, KC);
+}
+
+// Cooperative, fully coalesced write-out of a [rows][C] tile from LDS (row stride S bytes) to global memory (row stride
+// `gs` elements): 16 bytes per lane, consecutive lanes on consecutive addresses.  Per-lane 8-byte stores straight from
+// the MFMA accumulators touch 16 rows per instruction and are store-issue bound (measured 5 us for a 64x384 tile vs
+// <1 us through LDS).
+template <typename T>
+DHW_DEV void tile_copy_out(const char* lds, int S, T* gdst, int gs, int rows_valid, int C, int tid, int nthreads) {
+  constexpr int ES = sizeof(T), EPV = 16 / ES;
+  const int cpr = C / EPV;
+  const int total = rows_valid * cpr;
+  for (int id = tid; id < total; id += nthreads) {
+    const int r = id / cpr, cc = id - r * cpr;
+    *reinterpret_cast<uint4*>(gdst + (size_t)r * gs + cc * EPV) = *reinterpret_cast<const uint4*>(lds + r * S + cc * 16);
   }
-  int aoff = 0, kc = 0;
-  const int tap_step = stride - (KC - 1) * 32 * ES;
-  auto step = [&](int d, int knext) {
-    Frag<T> a[MT];
+}
+// same, but averaging row pairs (AvgPool1d(2), model.py:93): output row r = mean(tile rows 2r, 2r+1)
+template <typename T>
+DHW_DEV void tile_copy_out_pool(const char* lds, int S, T* gdst, int gs, int rows_valid_in, int C, int tid, int nthreads) {
+  constexpr int ES = sizeof(T), EPV = 16 / ES;
+  const int cpr = C / EPV;
+  const int total = (rows_valid_in / 2) * cpr;
+  for (int id = tid; id < total; id += nthreads) {
+    const int r = id / cpr, cc = id - r * cpr;
+    uint4 a = *reinterpret_cast<const uint4*>(lds + (2 * r) * S + cc * 16);
+    const uint4 b = *reinterpret_cast<const uint4*>(lds + (2 * r + 1) * S + cc * 16);
+    T* ea = reinterpret_cast<T*>(&a);
+    const T* eb = reinterpret_cast<const T*>(&b);
 #pragma unroll
-    for (int j = 0; j < MT; ++j) a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) mma32(acc[i][j], wq[d][i], a[j]);
-    const int kn = knext < KT ? knext : KT - 1;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) wq[d][i] = frag_load(wbase + ((size_t)i * KTS + kn) * 512);
-    const bool wrap = ++kc == KC;
-    aoff += wrap ? tap_step : 32 * ES;
-    kc = wrap ? 0 : kc;
-  };
-  int kt = 0;
-  for (; kt + D <= KT; kt += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) step(d, kt + d + D);
+    for (int k = 0; k < EPV; ++k) ea[k] = from_f<T>(0.5f * (to_f(ea[k]) + to_f(eb[k])));
+    *reinterpret_cast<uint4*>(gdst + (size_t)r * gs + cc * EPV) = a;
   }
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (kt + d < KT) step(d, KT - 1);
 }
 
 template <int NT, int MT>
@@ -84,7 +145,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
     s += __shfl_xor(s, 32);
     if (g == 0) red[wn * ROWS + row0 + j * 16 + l15] = s;
   }
-  __syncthreads();
+  lds_barrier();
   const float invn = 1.0f / (float)N;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -104,7 +165,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
     s += __shfl_xor(s, 32);
     if (g == 0) red[(WN + wn) * ROWS + row0 + j * 16 + l15] = s;
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     float s = 0.f;

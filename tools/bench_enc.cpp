@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost));
       printf("dbg=%d d=%d Lk=%d %s: %.2f us/launch (%d WGs); stage stamps of WG0 [us since start]:", dbg, d, Lk, which ? "enc_bc" : "enc_a ",
              ms * 1e3 / reps, B * ((Lk + 63) / 64));
-      const int s0 = which ? 16 : 0, s1 = which ? 24 : 7;
+      const int s0 = which ? 16 : 0, s1 = which ? 24 : 14;
       for (int k = s0; k <= s1; ++k) printf(" %.2f", h[k] ? (double)(h[k] - h[s0]) / 100.0 : -1.0);
       printf("\n");
     }
