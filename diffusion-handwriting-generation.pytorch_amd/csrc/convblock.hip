@@ -12,6 +12,7 @@
 // coalesced rows (+ the AvgPool1d side output).  Replaces three launches and the HBM/L2 round trips of h1/h2.
 //
 // bf16: 8 waves (2 per SIMD), BM = 64.  fp32 (parity mode): 4 waves, BM = 32 (LDS budget).
+#include <cstdlib>
 #include "gemm_core.h"
 #include "dhw_kernels.h"
 
@@ -37,9 +38,12 @@ void convblock_kernel(const ConvBlockParams p) {
   constexpr int BMO = BM - 2;            // output rows per workgroup
   constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
   constexpr int C1 = CO / 2;             // conv1 output channels
-  constexpr int WM1 = NW / 2, WM2 = NW / 4;                     // stage 1: waves WM1 x 2; stages 2,3: waves WM2 x 4
-  constexpr int MT1 = BM / WM1 / 16, NT1 = C1 / 2 / 16;
-  constexpr int MT2 = BM / WM2 / 16, NT2 = CO / 4 / 16;
+  // wave layouts (row groups x channel groups): stage 1 (conv1, C1 channels) and stages 2,3 (CO channels)
+  constexpr int WM1 = (BM / 16 < NW / 2) ? BM / 16 : NW / 2, WN1 = NW / WM1;
+  constexpr int WM2 = (BM / 32 < NW / 4) ? BM / 32 : NW / 4, WN2 = NW / WM2;
+  constexpr int MT1 = BM / WM1 / 16, NT1 = C1 / WN1 / 16;
+  constexpr int MT2 = BM / WM2 / 16, NT2 = CO / WN2 / 16;
+  static_assert(NT1 * 16 * WN1 == C1 && NT2 * 16 * WN2 == CO && MT1 >= 1 && MT2 >= 1, "unsupported tile / wave layout");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3;   // fewer fragments in flight for the widest block (VGPR budget)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -59,8 +63,8 @@ void convblock_kernel(const ConvBlockParams p) {
   const float* bet = gam + p.film_tot;
 
   // wave coordinates of the two layouts
-  const int wm1 = wave >> 1, wn1 = wave & 1, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
-  const int wm2 = wave >> 2, wn2 = wave & 3, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
+  const int wm1 = wave / WN1, wn1 = wave % WN1, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
+  const int wm2 = wave / WN2, wn2 = wave % WN2, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
 
@@ -230,6 +234,7 @@ hipError_t convblock_init() {
   if ((e = attr<bf16_t, 64, 128, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
   return attr<float, 32, 256, 4>();
@@ -241,7 +246,8 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
     switch (p.Cout) {
       case 128: return launch_t<bf16_t, 64, 128, 8>(p, st);
       case 192: return launch_t<bf16_t, 64, 192, 8>(p, st);
-      case 256: return launch_t<bf16_t, 64, 256, 8>(p, st);
+      case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
+        return (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) ? launch_t<bf16_t, 32, 256, 8>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);
     }
   } else {
     switch (p.Cout) {

@@ -116,24 +116,52 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   lds_barrier();
   STAMP(2);
 
-  {  // ---- cross attention over the Lt text keys; a1 overwrites q1 in place (same wave, same rows/columns)
-    constexpr int RG = BM / 16, HS = 8 / RG;   // waves: RG row groups x HS head sets
+  {  // ---- cross attention over the Lt text keys (K/V staged in LDS, 32 keys per block); a1 overwrites q1 in place
+    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBC = 32;
+    constexpr int SK = DM * ES + 16, SV = KBC * ES + 16;
+    char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    char* VT = KT + KBC * SK;
     const int rg = wave % RG, hs = wave / RG;
-    const T* k1 = reinterpret_cast<const T*>(p.k1);
-    const T* vt1 = reinterpret_cast<const T*>(p.vt1);
-#pragma unroll 1
-    for (int h = hs; h < H; h += HS) {
-      Frag<T> qf[2];
-      const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + h * 64 + 8 * g;
-      qf[0] = frag_load(qrow);
-      qf[1] = frag_load(qrow + 32);
-      f32x4 o[4];
-      attn_wave16_auto<T, 64>(qf, k1 + (size_t)(b * p.Lt + l15) * DM + h * 64, DM,
-                              vt1 + ((size_t)b * DM + h * 64 + l15) * p.lpadT + 4 * g, p.lpadT,
-                              p.text ? p.text + (size_t)b * p.Lt : nullptr, p.Lt, o);
-      T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+    Frag<T> qf[UMAX][2];
+    float mr[UMAX], lr[UMAX];
+    f32x4 o[UMAX][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + (h < H ? h : 0) * 64 + 8 * g;
+      qf[u][0] = frag_load(qrow);
+      qf[u][1] = frag_load(qrow + 32);
+      mr[u] = -INFINITY;
+      lr[u] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
+    }
+    const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
+    for (int kb = 0; kb < p.Lt; kb += KBC) {
+      attn_stage_kv<T, KBC>(KT, SK, VT, SV, reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM, DM,
+                            reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT, p.lpadT, DM, kb, tid, 512);
+      lds_barrier();
+#pragma unroll
+      for (int u = 0; u < UMAX; ++u) {
+        const int h = hs + u * HS;
+        if (h < H)
+          attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, trow,
+                                     p.Lt, mr[u], lr[u], o[u]);
+      }
+      lds_barrier();   // the staging tiles are rewritten by the next block
+    }
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      float l = lr[u];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      if (h < H) {
+        T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
+      }
     }
   }
   ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
@@ -253,24 +281,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   WRing<T, NT, RING> ring;
   EpiParams<NT> ep;
   STAMP(16);
-  {  // ---- self attention: q2, k2 from qk2, v2 from vt2 (all rows of the sample) -> a2 in LDS
-    constexpr int RG = BM / 16, HS = 8 / RG;   // waves: RG row groups x HS head sets
+  if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[40] = __builtin_amdgcn_s_memtime();
+  if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
+    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = 64;
+    constexpr int SK = DM * ES + 16, SV = KBS * ES + 16;
+    char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    char* VT = KT + KBS * SK;
     const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
-    const T* vt2 = reinterpret_cast<const T*>(p.vt2);
-#pragma unroll 1
-    for (int h = hs; h < H; h += HS) {
-      if (p.dbg & 1) break;
-      Frag<T> qf[2];
-      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + h * 64 + 8 * g;
-      qf[0] = frag_load(qrow);
-      qf[1] = frag_load(qrow + 32);
-      f32x4 o[4];
-      attn_wave16_auto<T, 64>(qf, qk + (size_t)(b * p.Lk + l15) * 2 * DM + DM + h * 64, 2 * DM,
-                              vt2 + ((size_t)b * DM + h * 64 + l15) * p.lpadX + 4 * g, p.lpadX, nullptr, p.Lk, o);
-      T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+    Frag<T> qf[UMAX][2];
+    float mr[UMAX], lr[UMAX];
+    f32x4 o[UMAX][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[t]);
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + (h < H ? h : 0) * 64 + 8 * g;
+      qf[u][0] = frag_load(qrow);
+      qf[u][1] = frag_load(qrow + 32);
+      mr[u] = -INFINITY;
+      lr[u] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
+    }
+    for (int kb = 0; kb < p.Lk; kb += KBS) {
+      attn_stage_kv<T, KBS>(KT, SK, VT, SV, qk + (size_t)b * p.Lk * 2 * DM + DM, 2 * DM,
+                            reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX, p.lpadX, DM, kb, tid, 512);
+      lds_barrier();
+#pragma unroll
+      for (int u = 0; u < UMAX; ++u) {
+        const int h = hs + u * HS;
+        if (h < H)
+          attn_block_lds<T, 64, KBS>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb,
+                                     nullptr, p.Lk, mr[u], lr[u], o[u]);
+      }
+      lds_barrier();   // the staging tiles are rewritten by the next block
+    }
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      float l = lr[u];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      if (h < H) {
+        T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
+      }
     }
   }
   ring.fill(reinterpret_cast<const T*>(p.w_d2) + wlane, KC);   // in flight across the barrier
@@ -361,6 +418,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.pool)
     tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);
+  if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[41] = __builtin_amdgcn_s_memtime();
 }
 
 template <typename T, int DM, int BM>
@@ -368,10 +426,11 @@ hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
   const int tiles = (p.Lk + BM - 1) / BM;
   const size_t red = 2 * 8 * BM * sizeof(float);
   if (which == 0) {
-    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red;
+    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red + (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16);
     hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   } else {
-    const size_t lds = (size_t)3 * BM * tile_stride<T>(DM) + red;
+    const size_t lds = (size_t)3 * BM * tile_stride<T>(DM) + red + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((enc_bc_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   }
   return hipGetLastError();
@@ -391,8 +450,18 @@ template <typename T, int DM>
 hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st) {
   const char* e = getenv("DHW_ENC_BM");
   const int force = e ? atoi(e) : 0;
-  const bool small = force ? force == 32 : (long)p.B * ((p.Lk + 63) / 64) < 256;
-  return small ? launch_pair<T, DM, 32>(p, which, st) : launch_pair<T, DM, 64>(p, which, st);
+  const char* t = getenv("DHW_ENC_WGS");
+  const long target = t ? atol(t) : 256;   // smallest tile count that still gives every CU a workgroup
+  int bm = 64;
+  if ((long)p.B * ((p.Lk + 63) / 64) < target) bm = 32;
+  if (DM % 128 == 0 && (long)p.B * ((p.Lk + 31) / 32) < target) bm = 16;   // (the 4x2 wave layout of DM=192 needs >= 32 rows)
+  if (force) bm = force;
+  // LDS budget (160 KiB): 3 row tiles + K/V staging in enc_bc; shrink the row tile until it fits
+  auto lds_bc = [](int m) { return (size_t)3 * m * tile_stride<T>(DM) + 2 * 8 * m * sizeof(float) + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16); };
+  while (bm > 16 && lds_bc(bm) > 160 * 1024) bm /= 2;
+  if (DM % 128 != 0 && bm < 32) bm = 32;
+  if (bm == 16) return launch_pair<T, DM, (DM % 128 == 0 ? 16 : 32)>(p, which, st);
+  return bm == 32 ? launch_pair<T, DM, 32>(p, which, st) : launch_pair<T, DM, 64>(p, which, st);
 }
 
 }  // namespace
@@ -404,7 +473,9 @@ hipError_t enclayer_init() {
   if ((e = attr<bf16_t, 384, 64>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 192, 32>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 256, 32>()) != hipSuccess) return e;
-  return attr<bf16_t, 384, 32>();
+  if ((e = attr<bf16_t, 384, 32>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 256, 16>()) != hipSuccess) return e;
+  return attr<bf16_t, 384, 16>();
 }
 
 bool enclayer_supported(int prec, int d, int heads) {

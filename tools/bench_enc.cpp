@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
              ms * 1e3 / reps, B * ((Lk + 63) / 64));
       const int s0 = which ? 16 : 0, s1 = which ? 24 : 14;
       for (int k = s0; k <= s1; ++k) printf(" %.2f", h[k] ? (double)(h[k] - h[s0]) / 100.0 : -1.0);
+      if (which) printf("  [shader clock %.2f GHz]", (double)(h[41] - h[40]) / ((double)(h[24] - h[16]) * 10.0));
       printf("\n");
     }
   }
