@@ -18,6 +18,11 @@
 
 namespace {
 
+#define STAMP(slot)                                                                                   \
+  do {                                                                                                \
+    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
 template <int NT>
 struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles, requested before the main loop
   f32x4 bias[NT], gam[NT], bet[NT];
@@ -68,6 +73,7 @@ void convblock_kernel(const ConvBlockParams p) {
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
 
+  STAMP(0);
   WRing<T, NT1, RING> ring1;
   Epi<NT1> ep1;
   ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
@@ -86,7 +92,7 @@ void convblock_kernel(const ConvBlockParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           v[k] = to_f(from_f<T>(p.in_w[(c + k) * 2] * s0 + p.in_w[(c + k) * 2 + 1] * s1 + p.in_b[c + k]));
-          sv[k] = silu_f(v[k]);
+          sv[k] = silu_t<T>(v[k]);
         }
       }
       store4(reinterpret_cast<T*>(XR + r * SX) + c, v);
@@ -116,7 +122,7 @@ void convblock_kernel(const ConvBlockParams p) {
         *reinterpret_cast<uint4*>(XR + dst[u]) = v[u];
         T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
-        for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_f(to_f(e[i])));
+        for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_t<T>(to_f(e[i])));
         *reinterpret_cast<uint4*>(XS + dst[u]) = v[u];
       }
     }
@@ -125,6 +131,7 @@ void convblock_kernel(const ConvBlockParams p) {
   for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
     *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   lds_barrier();
+  STAMP(1);
 
   WRing<T, NT2, RING> ring2;
   Epi<NT2> ep2;
@@ -134,6 +141,7 @@ void convblock_kernel(const ConvBlockParams p) {
     f32x4 acc[NT1][MT1];
     acc_zero(acc);
     ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+    STAMP(2);
     ring2.fill(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8, (C1 / 32) * 3);
     ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
 #pragma unroll
@@ -144,17 +152,19 @@ void convblock_kernel(const ConvBlockParams p) {
         const int srow = m0 - 1 + r;
         f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_f(v[k]) : 0.f;   // conv2 pads h1 with zeros
+        for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_t<T>(v[k]) : 0.f;   // conv2 pads h1 with zeros
         store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
       }
   }
   lds_barrier();
+  STAMP(3);
 
   // ---- stage 2: h2 = SiLU(FiLM2(conv2(h1))) for sample rows [m0, m0+BM) (the last 2 are discarded)
   {
     f32x4 acc[NT2][MT2];
     acc_zero(acc);
     ring2.template run<MT2>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
+    STAMP(4);
     ring2.fill(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * (CO / 32) * 64 + lane) * 8, CO / 32);
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
@@ -162,17 +172,19 @@ void convblock_kernel(const ConvBlockParams p) {
       for (int j = 0; j < MT2; ++j) {
         f32x4 v = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+        for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
         store4(reinterpret_cast<T*>(H2 + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, v);
       }
     ep2.load(p.b_fc, gam + p.f3, bet + p.f3, n2);
   }
   lds_barrier();
+  STAMP(5);
 
   // ---- stage 3: out = FiLM3(fc(h2)) + conv_skip(x)
   f32x4 acc[NT2][MT2];
   acc_zero(acc);
   ring2.template run<MT2>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
+  STAMP(6);
   ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
 #pragma unroll
   for (int i = 0; i < NT2; ++i)
@@ -180,7 +192,9 @@ void convblock_kernel(const ConvBlockParams p) {
     for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
   ep2.load(p.b_skip, nullptr, nullptr, n2);
   ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+  STAMP(7);
   lds_barrier();   // every wave is done with the operand tiles: reuse LDS for the output tile
+  STAMP(8);
 
   const int rows_valid = min(BMO, p.L - m0);
   if (p.out_f32) {
@@ -203,6 +217,7 @@ void convblock_kernel(const ConvBlockParams p) {
     if (p.pool)   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
       tile_copy_out_pool<T>(smem, SH2, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * CO, CO, rows_valid, CO, tid, NTHR);
   }
+  STAMP(9);
 }
 
 template <typename T, int BM, int CO>
@@ -232,6 +247,7 @@ hipError_t attr() {
 hipError_t convblock_init() {
   hipError_t e;
   if ((e = attr<bf16_t, 64, 128, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 128, 128, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
@@ -244,7 +260,11 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
   if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32)) return hipErrorInvalidValue;
   if (prec == PREC_BF16) {
     switch (p.Cout) {
-      case 128: return launch_t<bf16_t, 64, 128, 8>(p, st);
+      case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
+        const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
+                         !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
+        return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
+      }
       case 192: return launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
         return (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) ? launch_t<bf16_t, 32, 256, 8>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);

@@ -102,6 +102,11 @@ DHW_DEV void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v
 DHW_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 DHW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU for element type T: the bf16 path uses the 1-ulp hardware reciprocal (an IEEE fp32 divide is ~10 VALU
+// instructions and the result is rounded to bf16 anyway); the fp32 parity path keeps the exact divide.
+template <typename T> DHW_DEV float silu_t(float x);
+template <> DHW_DEV float silu_t<bf16_t>(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <> DHW_DEV float silu_t<float>(float x) { return silu_f(x); }
 DHW_DEV float to_f(bf16_t x) { return (float)x; }
 DHW_DEV float to_f(float x) { return x; }
 template <typename T> DHW_DEV T from_f(float x) { return (T)x; }

@@ -60,6 +60,7 @@ struct ConvBlockParams {
   int f1, f2, f3;                     // FiLM offsets of affine1..3
   void* out; int out_f32;             // [B*L, Cout]
   void* pool;                         // optional AvgPool1d(2) side output [B*L/2, Cout]
+  unsigned long long* stamps;         // diagnostics only: per-stage s_memrealtime of workgroup 0, or null
 };
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st);
 hipError_t convblock_init();

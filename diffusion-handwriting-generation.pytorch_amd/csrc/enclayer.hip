@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
         store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+        for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
         store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
       }
   }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < MT; ++j) {
           f32x4 v = acc[i][j] + ep.bias[i];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
           store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v);
         }
     }

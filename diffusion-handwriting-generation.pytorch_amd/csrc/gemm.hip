@@ -20,7 +20,8 @@
 //
 // A workgroup = 4 waves computes BM rows (of one sample) x BN channels; waves
 // are arranged WM x WN, each owning (BM/WM) x (BN/WN).
-#include "dhw_common.h"
+#include <algorithm>
+#include "gemm_core.h"
 #include "dhw_kernels.h"
 
 namespace {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         if (sg.silu) {
           T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
-          for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_f(to_f(e[i])));
+          for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_t<T>(to_f(e[i])));
         }
         if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
       }
@@ -230,10 +231,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] - mean[j]) * rstd[j];
   }
 
-  const int NV = p.N - p.n_store;   // transposed-V columns
+  // ---- final epilogue -> output tile in LDS -> whole coalesced rows to global (per-lane 8-byte stores straight from
+  // the accumulators touch 16 rows per instruction and are store-issue bound).  A workgroup's BN columns are either all
+  // regular output columns or all transposed-V columns (the launcher picks BN | n_store).
+  const bool vblock = nb0 >= p.n_store;
+  constexpr int SOT = BN * ES + 16, SOF = BN * 4 + 16, SVT = BM * ES + 16;
+  __syncthreads();   // every wave is done with the operand tiles: reuse LDS
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    const int n = (ntile0 + i) * 16 + 4 * g;
+    const int nl = (wn * (BN / WN)) + i * 16 + 4 * g;   // column inside the block
+    const int n = nb0 + nl;
     f32x4 ga = (f32x4){1, 1, 1, 1}, be = (f32x4){0, 0, 0, 0};
     if (p.film_mode == 1) {
       ga = *reinterpret_cast<const f32x4*>(p.gam + (long)(b / p.film_div) * p.film_bs + n);
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-      const int lrow = m0 + row0 + j * 16 + l15;
+      const int rl = row0 + j * 16 + l15;
+      const int lrow = m0 + rl;
       const bool valid = lrow < p.L;
       f32x4 v = acc[i][j];
       if (p.film_mode == 1) v = v * ga + be;
@@ -251,29 +259,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       }
       if (p.silu_out) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
-      if (n < p.n_store) {
-        if (valid) {
-          const size_t o = (size_t)(b * p.L + lrow) * p.n_store + n;
-          if (p.out_f32) store4(reinterpret_cast<float*>(p.out) + o, v);
-          else store4(reinterpret_cast<T*>(p.out) + o, v);
-        }
-        if (p.pool) {
-          // AvgPool1d(2) over rows (model.py:93): rows 2i,2i+1 sit in lanes l, l^1
-          f32x4 o;
+      if (vblock) {   // [channel][row], rows past L zero
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = 0.5f * (v[r] + __shfl_xor(v[r], 1));
-          if (valid && !(lane & 1))
-            store4(reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + (lrow >> 1)) * p.N + n, o);
-        }
-      } else if (lrow < p.vt_lpad) {
-        // V columns, stored key-contiguous for the attention kernel's PV product; rows past L stay zero
-        T* vt = reinterpret_cast<T*>(p.vt) + ((size_t)b * NV + (n - p.n_store)) * p.vt_lpad + lrow;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vt[(size_t)r * p.vt_lpad] = from_f<T>(valid ? v[r] : 0.f);
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<T*>(smem + (nl + r) * SVT + rl * ES) = from_f<T>(valid ? v[r] : 0.f);
+      } else if (p.out_f32) {
+        store4(reinterpret_cast<float*>(smem + rl * SOF) + nl, v);
+      } else {
+        store4(reinterpret_cast<T*>(smem + rl * SOT) + nl, v);
       }
     }
+  }
+  __syncthreads();
+  const int rows_valid = min(BM, p.L - m0);
+  if (vblock) {
+    constexpr int EPV = 16 / ES, PPR = BM / EPV;
+    const int NV = p.N - p.n_store;
+    T* vt = reinterpret_cast<T*>(p.vt) + ((size_t)b * NV + (nb0 - p.n_store)) * p.vt_lpad + m0;
+    for (int id = tid; id < BN * PPR; id += 256) {
+      const int ch = id / PPR, part = id - ch * PPR;
+      if (m0 + (part + 1) * EPV <= p.vt_lpad)
+        *reinterpret_cast<uint4*>(vt + (size_t)ch * p.vt_lpad + part * EPV) = *reinterpret_cast<const uint4*>(smem + ch * SVT + part * 16);
+    }
+  } else if (p.out_f32) {
+    tile_copy_out<float>(smem, SOF, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, 256);
+  } else {
+    tile_copy_out<T>(smem, SOT, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, 256);
+    if (p.pool)
+      tile_copy_out_pool<T>(smem, SOT, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * p.N + nb0, p.N, rows_valid, BN, tid, 256);
   }
 }
 
@@ -285,6 +299,8 @@ hipError_t launch_one(const GemmParams& p, hipStream_t st) {
   for (int s = 0; s < p.nseg; ++s)
     lds += (size_t)(BM + (p.seg[s].taps == 3 ? 2 : 0)) * (p.seg[s].C * sizeof(T) + 16);
   lds += 2 * WN * BM * sizeof(float);
+  const size_t out_tile = std::max((size_t)BM * (BN * 4 + 16), (size_t)BN * (BM * sizeof(T) + 16));
+  lds = std::max(lds, out_tile);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
   return hipGetLastError();
@@ -330,7 +346,8 @@ hipError_t gemm_init() {
 
 void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
   int bm = 32;
-  if (prec == PREC_BF16 && p.L >= 48) bm = 64;
+  // 64-row tiles unless 32-row tiles waste markedly fewer padded rows (tiles never span samples), e.g. L = 70
+  if (prec == PREC_BF16 && p.L >= 48 && (((p.L + 63) / 64) * 64) * 4 <= (((p.L + 31) / 32) * 32) * 5) bm = 64;
   const int cands[6] = {384, 256, 192, 128, 96, 64};
   int bn = 0;
   if (p.ln) {
@@ -338,15 +355,17 @@ void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
   } else {
     const long tiles = (long)p.B * ((p.L + bm - 1) / bm);
     // largest BN dividing N that still yields >= 512 workgroups; else the smallest divisor >= 128 (or the only one)
+    // a workgroup's columns must be all regular or all transposed-V: BN divides n_store (and N - n_store)
+    auto ok = [&](int c) { return p.N % c == 0 && p.n_store % c == 0; };
     for (int c : cands)
-      if (p.N % c == 0 && tiles * (p.N / c) >= 512) { bn = c; break; }
+      if (ok(c) && tiles * (p.N / c) >= 512) { bn = c; break; }
     if (!bn) {
       for (int k = 5; k >= 0; --k)
-        if (p.N % cands[k] == 0 && (cands[k] >= 128 || p.N == cands[k])) { bn = cands[k]; break; }
+        if (ok(cands[k]) && (cands[k] >= 128 || p.N == cands[k])) { bn = cands[k]; break; }
     }
     if (!bn)
       for (int k = 5; k >= 0; --k)
-        if (p.N % cands[k] == 0) { bn = cands[k]; break; }
+        if (ok(cands[k])) { bn = cands[k]; break; }
   }
   *BM = bm;
   *BN = bn;
