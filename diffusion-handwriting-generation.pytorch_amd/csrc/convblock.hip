@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include "gemm_core.h"
 #include "dhw_kernels.h"
+#include "heads_core.h"
 
 namespace {
 
@@ -205,7 +206,31 @@ void convblock_kernel(const ConvBlockParams p) {
       for (int j = 0; j < MT2; ++j)
         store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
     lds_barrier();
-    tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
+    if (p.out)
+      tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
+    if (p.fuse_heads) {
+      // eps / pen heads (model.py:179-182) + scheduler step straight from the fp32 tile: 4 lanes per stroke row
+      const int r = tid >> 2, q = tid & 3;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      if (r < rows_valid) {
+        const float* xr = reinterpret_cast<const float*>(smem + r * SO);
+        for (int c = q * 4; c < CO; c += 16) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.hp.w_out + c);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.hp.w_out + CO + c);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(p.hp.w_pen + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { a0 += v[k] * w0[k]; a1 += v[k] * w1[k]; a2 += v[k] * w2[k]; }
+        }
+      }
+#pragma unroll
+      for (int o = 2; o; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+      }
+      if (r < rows_valid && q == 0) heads_finish(p.hp, (long)b * p.L + m0 + r, a0, a1, a2);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
@@ -257,7 +282,7 @@ hipError_t convblock_init() {
 }
 
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) {
-  if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32)) return hipErrorInvalidValue;
+  if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32) || (p.fuse_heads && !p.out_f32) || (!p.out && !p.fuse_heads)) return hipErrorInvalidValue;
   if (prec == PREC_BF16) {
     switch (p.Cout) {
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)

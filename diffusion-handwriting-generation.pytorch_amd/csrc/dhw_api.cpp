@@ -197,6 +197,7 @@ struct dhw_handle {
   // graph cache for dhw_sample: the graph only touches library-owned staging buffers, so it is keyed by the
   // problem shape alone and replays for any caller pointers
   bool use_graph = true;
+  bool fuse_heads = true;       // dec1 evaluates heads + scheduler step (env DHW_FUSE_HEADS=0 -> separate launch)
   bool plane = true;            // all-steps text plane in dhw_sample (env DHW_PLANE=0 -> text side inside every step)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
@@ -512,6 +513,7 @@ struct Ctx {
   int film_div = 1;    // samples per FiLM row
   int in_B = 0;        // batch of the sigma-independent inputs (0 = B); the text plane replicates them over steps
   std::string sfx;     // suffix of the text-side output buffers: "" (per call) or ".T" (all-steps plane)
+  const HeadsParams* fhp = nullptr;   // sampling loop: dec1 evaluates the heads + scheduler step itself
   bool fuse_input = false;  // enc1 evaluates input_dense while staging (sampling loop); forward() keeps the tap
   bool use_plane = false;   // stroke path reads the text K/V of step `plane_step` from the plane
   long plane_step = 0;
@@ -588,6 +590,13 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot;
     q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
     q.out = out; q.out_f32 = out_f32; q.pool = pool;
+    if (c.fhp && n == "dec1") {
+      q.fuse_heads = 1;
+      q.hp = *c.fhp;
+      q.hp.w_out = h->out_w; q.hp.b_out = h->out_b; q.hp.w_pen = h->pen_w; q.hp.b_pen = h->pen_b;
+      q.hp.L = L;
+      q.out = nullptr;   // the fp32 activation never leaves LDS
+    }
     if (!c.err) {
       const double rows = (double)c.B * L;
       Launch l(h, c.st, "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout),
@@ -1019,6 +1028,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
     if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
   if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
   if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
+  if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1226,7 +1236,6 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
     c.use_plane = h->plane;
     c.plane_step = step % TC;
     if (!h->plane) text_style_dynamic(c);
-    stroke_path(c, w->d_xt, text);
     HeadsParams hp{};
     hp.eps = nullptr;
     hp.pen = nullptr;
@@ -1250,7 +1259,10 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
       hp.add_noise = i != 0;   // inference.py:92
     }
     if (i == 0) hp.out3 = out;
-    launch_heads_for(c, hp);
+    const bool fh = h->fuse && h->fuse_heads;
+    c.fhp = fh ? &hp : nullptr;
+    stroke_path(c, w->d_xt, text);
+    if (!fh) launch_heads_for(c, hp);
     if (c.err) return c.err;
   }
   return c.err;
@@ -1348,7 +1360,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if (!graph) {
     rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipStream_t cs;

@@ -48,6 +48,25 @@ hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st);
 // tile actually chosen (for tests / work accounting)
 void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN);
 
+// heads (+ optional fused scheduler step).  x: fp32 [rows, C] (dec1 output).
+struct HeadsParams {
+  const float* x; long rows; int C;
+  const float* w_out; const float* b_out;   // [2,C],[2]
+  const float* w_pen; const float* b_pen;   // [1,C],[1]
+  float* eps; float* pen;                   // [rows,2], [rows]  (pen may be null)
+  // fused scheduler step (null xt = none): xt <- step(xt, eps, z), reference operation order
+  float* xt;               // [rows,2] fp32 sampler state, updated in place
+  const float* z;          // [rows,2] external noise or null (=> Philox)
+  int mode;                // 0 new (utils/nn.py:110-112), 1 standard (utils/nn.py:84-87)
+  int add_noise;           // standard mode: bool(i) (inference.py:92); new mode: always 1
+  float k0;                // sqrt(1 - abar_i)
+  float k1;                // new: sqrt(1 - beta_i);  standard: 1 / sqrt(1 - beta_i)
+  float k2;                // new: sqrt(1 - abar_next);  standard: sqrt(beta_i)
+  float k3;                // standard: beta_i
+  const uint64_t* seed_ptr; int sample_off; int L; int iter;   // Philox: device [seed, first_sample]; counter = (sample, pos, iter)
+  float* out3;             // optional [rows,3] final cat(x, pen)
+};
+
 // ---------------------------------------------------------------- fused ConvBlock (cnn.py:64-87), one launch
 struct ConvBlockParams {
   const void* x;                      // block input [B*L, Cin]
@@ -60,6 +79,8 @@ struct ConvBlockParams {
   int f1, f2, f3;                     // FiLM offsets of affine1..3
   void* out; int out_f32;             // [B*L, Cout]
   void* pool;                         // optional AvgPool1d(2) side output [B*L/2, Cout]
+  int fuse_heads;                     // dec1 in the sampling loop: evaluate the eps/pen heads + scheduler step from the fp32
+  HeadsParams hp;                     //   output tile in LDS (hp.x/rows/C unused); `out` may then be null (no activation write)
   unsigned long long* stamps;         // diagnostics only: per-stage s_memrealtime of workgroup 0, or null
 };
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st);
@@ -115,24 +136,6 @@ hipError_t launch_cast(int prec, const float* in, long n, void* out, hipStream_t
 hipError_t launch_input_dense(int prec, const float* strokes, long rows, const float* w, const float* b,
                               int C, void* out, hipStream_t st);
 
-// heads (+ optional fused scheduler step).  x: fp32 [rows, C] (dec1 output).
-struct HeadsParams {
-  const float* x; long rows; int C;
-  const float* w_out; const float* b_out;   // [2,C],[2]
-  const float* w_pen; const float* b_pen;   // [1,C],[1]
-  float* eps; float* pen;                   // [rows,2], [rows]  (pen may be null)
-  // fused scheduler step (null xt = none): xt <- step(xt, eps, z), reference operation order
-  float* xt;               // [rows,2] fp32 sampler state, updated in place
-  const float* z;          // [rows,2] external noise or null (=> Philox)
-  int mode;                // 0 new (utils/nn.py:110-112), 1 standard (utils/nn.py:84-87)
-  int add_noise;           // standard mode: bool(i) (inference.py:92); new mode: always 1
-  float k0;                // sqrt(1 - abar_i)
-  float k1;                // new: sqrt(1 - beta_i);  standard: 1 / sqrt(1 - beta_i)
-  float k2;                // new: sqrt(1 - abar_next);  standard: sqrt(beta_i)
-  float k3;                // standard: beta_i
-  const uint64_t* seed_ptr; int sample_off; int L; int iter;   // Philox: device [seed, first_sample]; counter = (sample, pos, iter)
-  float* out3;             // optional [rows,3] final cat(x, pen)
-};
 hipError_t launch_heads(const HeadsParams& p, hipStream_t st);
 // x_T ~ N(0,1) from Philox, same keying as the per-step draws (iter = -1)
 hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st);
