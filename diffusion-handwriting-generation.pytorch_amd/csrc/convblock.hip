@@ -37,8 +37,10 @@ struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles,
   }
 };
 
-template <typename T, int BM, int CO, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4 < 2 ? 2 : NW / 4)))
+// OCC = workgroups meant to be co-resident per CU (VGPR budget 512 / (OCC * NW / 4) per lane): with 2, one workgroup's
+// VALU-heavy epilogue / staging overlaps the other's MFMA phases.
+template <typename T, int BM, int CO, int NW, int OCC = 1>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr int BMO = BM - 2;            // output rows per workgroup
@@ -50,7 +52,7 @@ void convblock_kernel(const ConvBlockParams p) {
   constexpr int MT1 = BM / WM1 / 16, NT1 = C1 / WN1 / 16;
   constexpr int MT2 = BM / WM2 / 16, NT2 = CO / WN2 / 16;
   static_assert(NT1 * 16 * WN1 == C1 && NT2 * 16 * WN2 == CO && MT1 >= 1 && MT2 >= 1, "unsupported tile / wave layout");
-  constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3;   // fewer fragments in flight for the widest block (VGPR budget)
+  constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / OCC;   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,18 +254,18 @@ size_t lds_bytes(int Cin) {
   return ops > outf ? ops : outf;
 }
 
-template <typename T, int BM, int CO, int NW>
+template <typename T, int BM, int CO, int NW, int OCC = 1>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st) {
   const size_t lds = lds_bytes<T, BM, CO>(p.Cin);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW>
+template <typename T, int BM, int CO, int NW, int OCC = 1>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -273,6 +275,8 @@ hipError_t convblock_init() {
   hipError_t e;
   if ((e = attr<bf16_t, 64, 128, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 128, 128, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 128, 8, 2>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 192, 8, 2>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
@@ -288,9 +292,14 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
         const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
+        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 128, 8, 2>(p, st);
         return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
       }
-      case 192: return launch_t<bf16_t, 64, 192, 8>(p, st);
+      case 192:
+        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 192, 8, 2>(p, st);
+        return launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
         return (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) ? launch_t<bf16_t, 32, 256, 8>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);
     }

@@ -256,3 +256,71 @@ def test_cpu_inputs_are_moved_and_results_come_back_on_cpu():
     eps, pen, none = m(strokes, text, sigma, style_vector)
     assert eps.shape == (8, 400, 2) and pen.shape == (8, 400) and none is None
     assert eps.device.type == "cpu" and torch.isfinite(eps).all() and ((pen > 0) & (pen < 1)).all()
+
+
+def _fresh_model(prec, env, **kw):
+    """A model whose handle is created under the given library switches (they are read at dhw_create)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        m = dhg_amd.DiffusionModel(2, precision=prec, max_B=kw.get("B", 4), max_L=kw.get("L", 488), max_Lt=kw.get("Lt", 40)).eval()
+        m.load_state_dict(_sd(2), strict=True)
+        # force handle creation now, while the switches are set
+        inp = spec.synthetic_inputs(1, 8, 2, seed=1)
+        fwd(m, inp, torch.full((1, 1), 0.5))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return m
+
+
+def test_one_launch_per_gemm_path_matches_reference_golden(golden_dir):
+    """bf16 with the fused block kernels switched off (DHW_FUSE=0): the generic GEMM + stand-alone attention path."""
+    g = np.load(os.path.join(golden_dir, "fwd_pad.npz"))
+    B, L, Lt = int(g["B"]), int(g["L"]), int(g["Lt"])
+    m = _fresh_model("bf16", {"DHW_FUSE": "0"})
+    inp = spec.synthetic_inputs(B, L, Lt, seed=int(g["seed"]), pad=int(g["pad"]))
+    alpha = dhg_amd.get_alpha_set()
+    eps, pen = fwd(m, inp, torch.sqrt(alpha[30]) * torch.ones((B, 1, 1)))
+    assert np.abs(eps - g["eps_i30"]).max() < TOL["bf16"]["eps"]
+    assert np.abs(pen - g["pen_i30"]).max() < TOL["bf16"]["pen"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_sampler_switches_do_not_change_the_samples(prec):
+    """The all-steps text plane, the heads fused into dec1 and the enc1-fused input Linear only reorder the evaluation:
+    every switch combination must give the same samples (same arithmetic per element)."""
+    B, L, Lt, T = 3, 80, 9, 7
+    inp = spec.synthetic_inputs(B, L, Lt, seed=12, pad=1, T=T)
+    tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
+    outs = {}
+    for name, env in (("default", {}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
+                      ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
+        m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
+        outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
+    assert torch.equal(outs["default"], outs["no_plane"])
+    tol = 1e-4 if prec == "fp32" else 0.15   # fused vs unfused block kernels round intermediates at different points
+    assert (outs["default"] - outs["no_fused_heads"]).abs().max().item() < tol
+    assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
+
+
+def test_long_sequence_config_matches_oracle():
+    """BASELINE configs[3] shape class (L=1000, 62 tokens) with a short schedule: exercises multi-block attention
+    (L/2 = 500 keys), several row tiles per sample at every level and the T-generalised schedule."""
+    B, L, Lt, T = 1, 1000, 62, 3
+    m = dhg_amd.DiffusionModel(2, precision="fp32", max_B=B, max_L=L, max_Lt=Lt).eval()
+    m.load_state_dict(_sd(2))
+    inp = spec.synthetic_inputs(B, L, Lt, seed=44, T=T)
+    noise = torch.from_numpy(inp["noise"])
+    ref, _ = ref_cpu.sample(_sd(2), torch.from_numpy(inp["text"]), torch.from_numpy(inp["style"]), L, noise, T=T)
+    out = dhg_amd.sample(m, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=T,
+                         noise=noise.cuda()).cpu()
+    assert (out - ref).abs().max().item() < 1e-4
+    mb = dhg_amd.DiffusionModel(2, precision="bf16", max_B=B, max_L=L, max_Lt=Lt).eval()
+    mb.load_state_dict(_sd(2))
+    outb = dhg_amd.sample(mb, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=T,
+                          noise=noise.cuda()).cpu()
+    assert torch.isfinite(outb).all() and (outb - ref).abs().max().item() < 0.1
