@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdhw_hip.so")
+# DHW_LIB: alternative build of the SAME library (A/B runs of two builds on one GPU box); default = the in-tree build
+LIB_PATH = os.environ.get("DHW_LIB") or os.path.join(HERE, "libdhw_hip.so")
 
 DHW_F32, DHW_BF16, DHW_F16, DHW_F64 = 0, 1, 2, 3
 PREC_BF16, PREC_F32 = 0, 1
