@@ -46,12 +46,20 @@ void convblock_kernel(const ConvBlockParams p) {
   constexpr int BMO = BM - 2;            // output rows per workgroup
   constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
   constexpr int C1 = CO / 2;             // conv1 output channels
-  // wave layouts (row groups x channel groups): stage 1 (conv1, C1 channels) and stages 2,3 (CO channels)
-  constexpr int WM1 = (BM / 16 < NW / 2) ? BM / 16 : NW / 2, WN1 = NW / WM1;
-  constexpr int WM2 = (BM / 32 < NW / 4) ? BM / 32 : NW / 4, WN2 = NW / WM2;
-  constexpr int MT1 = BM / WM1 / 16, NT1 = C1 / WN1 / 16;
-  constexpr int MT2 = BM / WM2 / 16, NT2 = CO / WN2 / 16;
-  static_assert(NT1 * 16 * WN1 == C1 && NT2 * 16 * WN2 == CO && MT1 >= 1 && MT2 >= 1, "unsupported tile / wave layout");
+  // Wave layouts (row groups x channel groups): stage 1 (conv1, C1 channels) and stages 2,3 (CO channels).
+  // Every wave streams its OWN weight fragments from L2, so waves that differ only in their row group fetch the same
+  // bytes again: with 4 row groups the conv1 stage of dec3 pulled 4 x 295 KB through the CU's 64 B/clk L1 path and ran
+  // 9 us where 2 us of MFMA work was issued.  With 8 waves the channels are therefore split as finely as the 16-channel
+  // MFMA tile allows (one row group whenever there are >= 6 channel tiles; waves beyond the tile count idle), and each
+  // wave covers all rows.  (fp32 parity mode, 4 waves, keeps the 2x2 / 1x4 layouts.)
+  constexpr int T1 = C1 / 16, T2 = CO / 16;                                   // 16-channel tiles per stage
+  constexpr int WN1 = NW == 8 ? (T1 >= 8 ? 8 : (T1 == 6 ? 6 : 4)) : 2;
+  constexpr int WM1 = NW == 8 ? (T1 >= 6 ? 1 : 2) : 2;
+  constexpr int WN2 = NW == 8 ? (T2 % 8 == 0 ? 8 : 6) : 4;
+  constexpr int WM2 = 1;
+  constexpr int MT1 = BM / WM1 / 16, NT1 = T1 / WN1;
+  constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
+  static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / OCC;   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -71,16 +79,19 @@ void convblock_kernel(const ConvBlockParams p) {
   const float* bet = gam + p.film_tot;
 
   // wave coordinates of the two layouts
-  const int wm1 = wave / WN1, wn1 = wave % WN1, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
-  const int wm2 = wave / WN2, wn2 = wave % WN2, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
+  const bool act1 = wave < WM1 * WN1, act2 = wave < WM2 * WN2;   // idle waves only join the barriers / copies
+  const int wm1 = act1 ? wave / WN1 : 0, wn1 = act1 ? wave % WN1 : 0, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
+  const int wm2 = act2 ? wave / WN2 : 0, wn2 = act2 ? wave % WN2 : 0, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
 
   STAMP(0);
   WRing<T, NT1, RING> ring1;
   Epi<NT1> ep1;
-  ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
-  ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
+  if (act1) {
+    ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
+    ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
+  }
 
   // ---- stage 0: x tile -> LDS (raw + SiLU), zero outside the sample ('same' padding)
   if (p.strokes) {
@@ -143,27 +154,31 @@ void convblock_kernel(const ConvBlockParams p) {
   {
     f32x4 acc[NT1][MT1];
     acc_zero(acc);
-    ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+    if (act1) ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
     STAMP(2);
-    ring2.fill(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8, (C1 / 32) * 3);
-    ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
+    if (act2) {
+      ring2.fill(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8, (C1 / 32) * 3);
+      ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
+    }
+    if (act1) {
 #pragma unroll
-    for (int i = 0; i < NT1; ++i)
+      for (int i = 0; i < NT1; ++i)
 #pragma unroll
-      for (int j = 0; j < MT1; ++j) {
-        const int r = row01 + j * 16 + l15;
-        const int srow = m0 - 1 + r;
-        f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
+        for (int j = 0; j < MT1; ++j) {
+          const int r = row01 + j * 16 + l15;
+          const int srow = m0 - 1 + r;
+          f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_t<T>(v[k]) : 0.f;   // conv2 pads h1 with zeros
-        store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
-      }
+          for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_t<T>(v[k]) : 0.f;   // conv2 pads h1 with zeros
+          store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
+        }
+    }
   }
   lds_barrier();
   STAMP(3);
 
   // ---- stage 2: h2 = SiLU(FiLM2(conv2(h1))) for sample rows [m0, m0+BM) (the last 2 are discarded)
-  {
+  if (act2) {
     f32x4 acc[NT2][MT2];
     acc_zero(acc);
     ring2.template run<MT2>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
@@ -186,15 +201,17 @@ void convblock_kernel(const ConvBlockParams p) {
   // ---- stage 3: out = FiLM3(fc(h2)) + conv_skip(x)
   f32x4 acc[NT2][MT2];
   acc_zero(acc);
-  ring2.template run<MT2>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
-  STAMP(6);
-  ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
+  if (act2) {
+    ring2.template run<MT2>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
+    STAMP(6);
+    ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
 #pragma unroll
-  for (int i = 0; i < NT2; ++i)
+    for (int i = 0; i < NT2; ++i)
 #pragma unroll
-    for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
-  ep2.load(p.b_skip, nullptr, nullptr, n2);
-  ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+      for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
+    ep2.load(p.b_skip, nullptr, nullptr, n2);
+    ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+  }
   STAMP(7);
   lds_barrier();   // every wave is done with the operand tiles: reuse LDS for the output tile
   STAMP(8);
@@ -202,11 +219,13 @@ void convblock_kernel(const ConvBlockParams p) {
   const int rows_valid = min(BMO, p.L - m0);
   if (p.out_f32) {
     constexpr int SO = CO * 4 + 16;
+    if (act2) {
 #pragma unroll
-    for (int i = 0; i < NT2; ++i)
+      for (int i = 0; i < NT2; ++i)
 #pragma unroll
-      for (int j = 0; j < MT2; ++j)
-        store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+        for (int j = 0; j < MT2; ++j)
+          store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+    }
     lds_barrier();
     if (p.out)
       tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
@@ -234,11 +253,13 @@ void convblock_kernel(const ConvBlockParams p) {
       if (r < rows_valid && q == 0) heads_finish(p.hp, (long)b * p.L + m0 + r, a0, a1, a2);
     }
   } else {
+    if (act2) {
 #pragma unroll
-    for (int i = 0; i < NT2; ++i)
+      for (int i = 0; i < NT2; ++i)
 #pragma unroll
-      for (int j = 0; j < MT2; ++j)
-        store4(reinterpret_cast<T*>(smem + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+        for (int j = 0; j < MT2; ++j)
+          store4(reinterpret_cast<T*>(smem + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+    }
     lds_barrier();
     tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.pool)   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
