@@ -12,6 +12,7 @@
 // coalesced rows (+ the AvgPool1d side output).  Replaces three launches and the HBM/L2 round trips of h1/h2.
 //
 // bf16: 8 waves (2 per SIMD), BM = 64.  fp32 (parity mode): 4 waves, BM = 32 (LDS budget).
+#include <algorithm>
 #include <cstdlib>
 #include "gemm_core.h"
 #include "dhw_kernels.h"
@@ -39,7 +40,9 @@ struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles,
 
 // OCC = workgroups meant to be co-resident per CU (VGPR budget 512 / (OCC * NW / 4) per lane): with 2, one workgroup's
 // VALU-heavy epilogue / staging overlaps the other's MFMA phases.
-template <typename T, int BM, int CO, int NW, int OCC = 1>
+// UPC = 0, or the block's input width Cin when the input itself is produced here (decoder blocks):
+// x = Upsample(low) + skip_conv(h) (model.py:169-175), one more 3-tap GEMM stage in front of the block.
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
@@ -88,13 +91,80 @@ void convblock_kernel(const ConvBlockParams p) {
   STAMP(0);
   WRing<T, NT1, RING> ring1;
   Epi<NT1> ep1;
-  if (act1) {
+  if (UPC == 0 && act1) {
     ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
     ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
   }
 
   // ---- stage 0: x tile -> LDS (raw + SiLU), zero outside the sample ('same' padding)
-  if (p.strokes) {
+  if constexpr (UPC != 0) {
+    // decoder input: x[r] = low[r/2] + b + sum_tap Wsk[tap] h[r-1+tap], rows [m0-2, m0-2+RX) rounded up to 16-row tiles.
+    // h rows [m0-3, m0-3+RH) are staged where h1/h2 will live later; the up-sampled low rows go straight into the XR
+    // tile, and the GEMM epilogue adds the convolution in place (same lane reads and writes an element).
+    constexpr int RXP = (RX + 15) / 16 * 16, RH = RXP + 2, MTU = RXP / 16;
+    constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 6, NTU = TU / WNU;
+    static_assert(NTU * WNU == TU && NW == 8, "unsupported input width");
+    const bool actu = wave < WNU;
+    const int ntu0 = (actu ? wave : 0) * NTU, nu = ntu0 * 16 + 4 * g;
+    const int Ch = p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);
+    char* HS = H1;
+    WRing<T, NTU, RING> ringu;
+    Epi<NTU> epu;
+    if (actu) {
+      ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
+      epu.load(p.up_b, nullptr, nullptr, nu);
+    }
+    {
+      const int cpr = Ch * ES / 16;
+      const char* src = reinterpret_cast<const char*>(p.up_h);
+      for (int id = tid; id < RH * cpr; id += NTHR) {
+        const int r = id / cpr, cc = id - r * cpr;
+        const int lrow = m0 - 3 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lrow >= 0 && lrow < p.L) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Ch) * ES + (size_t)cc * 16);
+        *reinterpret_cast<uint4*>(HS + r * SHh + cc * 16) = v;
+      }
+      const int cpx = Cin * ES / 16;
+      const char* low = reinterpret_cast<const char*>(p.up_low);
+      for (int id = tid; id < RX * cpx; id += NTHR) {
+        const int r = id / cpx, cc = id - r * cpx;
+        const int lrow = m0 - 2 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lrow >= 0 && lrow < p.L)
+          v = *reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * Cin) * ES + (size_t)cc * 16);
+        *reinterpret_cast<uint4*>(XR + r * SX + cc * 16) = v;
+      }
+    }
+    lds_barrier();
+    f32x4 acc[NTU][MTU];
+    acc_zero(acc);
+    if (actu) ringu.template run<MTU>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
+    if (act1) {
+      ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during the epilogue
+      ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
+    }
+    if (actu) {
+#pragma unroll
+      for (int i = 0; i < NTU; ++i)
+#pragma unroll
+        for (int j = 0; j < MTU; ++j) {
+          const int r = j * 16 + l15;
+          const int lrow = m0 - 2 + r;
+          if (r < RX) {
+            T* xp = reinterpret_cast<T*>(XR + r * SX) + nu + 16 * i;
+            f32x4 v = acc[i][j] + epu.bias[i] + load4(xp), sv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[k] = (lrow >= 0 && lrow < p.L) ? to_f(from_f<T>(v[k])) : 0.f;   // the block's own 'same' padding
+              sv[k] = silu_t<T>(v[k]);
+            }
+            store4(xp, v);
+            store4(reinterpret_cast<T*>(XS + r * SX) + nu + 16 * i, sv);
+          }
+        }
+    }
+    lds_barrier();   // HS (aliasing h1) is rewritten just below
+  } else if (p.strokes) {
     // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load
     const int cpr = Cin / 4;   // 4 channels per item
     for (int id = tid; id < RX * cpr; id += NTHR) {
@@ -269,24 +339,26 @@ void convblock_kernel(const ConvBlockParams p) {
 }
 
 template <typename T, int BM, int CO>
-size_t lds_bytes(int Cin) {
-  const size_t ops = (size_t)2 * (BM + 2) * tile_stride<T>(Cin) + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * tile_stride<T>(CO);
+size_t lds_bytes(int Cin, int up_cin = 0) {
+  const size_t xt = (size_t)2 * (BM + 2) * tile_stride<T>(Cin);
+  const size_t ops = xt + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * tile_stride<T>(CO);
   const size_t outf = (size_t)BM * (CO * 4 + 16);
-  return ops > outf ? ops : outf;
+  const size_t up = up_cin ? xt + (size_t)((BM + 2 + 15) / 16 * 16 + 2) * tile_stride<T>(up_cin) : 0;   // x tiles + staged h rows
+  return std::max(ops, std::max(outf, up));
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st) {
-  const size_t lds = lds_bytes<T, BM, CO>(p.Cin);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
+  if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32))) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -301,6 +373,10 @@ hipError_t convblock_init() {
   if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 128, 8, 1, 192>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 128, 128, 8, 1, 192>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 192, 8, 1, 256>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 256, 8, 1, 384>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
   return attr<float, 32, 256, 4>();
@@ -308,6 +384,16 @@ hipError_t convblock_init() {
 
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) {
   if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32) || (p.fuse_heads && !p.out_f32) || (!p.out && !p.fuse_heads)) return hipErrorInvalidValue;
+  if (p.up_h) {   // decoder block with the fused Upsample + skip_conv input stage (bf16 only)
+    if (prec != PREC_BF16 || p.strokes || !p.up_w || !p.up_b || !p.up_low) return hipErrorInvalidValue;
+    if (p.Cout == 128 && p.Cin == 192) {
+      const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
+      return big ? launch_t<bf16_t, 128, 128, 8, 1, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192>(p, st);
+    }
+    if (p.Cout == 192 && p.Cin == 256) return launch_t<bf16_t, 64, 192, 8, 1, 256>(p, st);
+    if (p.Cout == 256 && p.Cin == 384) return launch_t<bf16_t, 64, 256, 8, 1, 384>(p, st);
+    return hipErrorInvalidValue;
+  }
   if (prec == PREC_BF16) {
     switch (p.Cout) {
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)

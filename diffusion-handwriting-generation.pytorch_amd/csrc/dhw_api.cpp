@@ -199,6 +199,7 @@ struct dhw_handle {
   bool use_graph = true;
   bool fuse_heads = true;       // dec1 evaluates heads + scheduler step (env DHW_FUSE_HEADS=0 -> separate launch)
   bool plane = true;            // all-steps text plane in dhw_sample (env DHW_PLANE=0 -> text side inside every step)
+  bool fuse_up = true;          // decoder ConvBlocks evaluate Upsample + skip_conv while staging (env DHW_FUSE_UP=0 -> separate GEMM)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
@@ -591,13 +592,17 @@ void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, 
   c.h->taps[name] = Tap{BUF(c, bufname), rows, cols, f32};
 }
 
-// cnn.py:64-87 as three fused GEMM launches
+// decoder input produced inside the block: Upsample(low) + skip_conv(hskip)  (model.py:169-175)
+struct UpIn { const void* hskip; const void* w; const float* b; int cin; const void* low; };
+
+// cnn.py:64-87 as one fused launch (or three fused GEMM launches)
 void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
-                void* pool, const float* strokes = nullptr) {
+                void* pool, const float* strokes = nullptr, const UpIn* up = nullptr) {
   dhw_handle* h = c.h;
   if (h->fuse) {
     ConvBlockParams q{};
     q.strokes = strokes; q.in_w = h->in_w; q.in_b = h->in_b;
+    if (up) { q.up_h = up->hskip; q.up_cin = up->cin; q.up_w = up->w; q.up_b = up->b; q.up_low = up->low; }
     q.x = x; q.B = c.B; q.L = L; q.Cin = w.cin; q.Cout = w.cout;
     q.w_c1 = w.w_c1; q.w_c2 = w.w_c2; q.w_fc = w.w_fc; q.w_skip = w.w_skip;
     q.b_c1 = w.b_c1; q.b_c2 = w.b_c2; q.b_fc = w.b_fc; q.b_skip = w.b_skip;
@@ -613,9 +618,10 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     }
     if (!c.err) {
       const double rows = (double)c.B * L;
-      Launch l(h, c.st, "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout),
-               rows * (w.cin * h->es + w.cout * (out_f32 ? 4.0 : (double)h->es) * (pool ? 1.5 : 1.0)) +
-                   (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout) * h->es);
+      const double upf = up ? 3.0 * up->cin * w.cin : 0.0;   // skip_conv MACs per row
+      Launch l(h, c.st, "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf),
+               rows * ((up ? up->cin + 0.5 * w.cin : w.cin) * h->es + w.cout * (out_f32 ? 4.0 : (double)h->es) * (pool ? 1.5 : 1.0)) +
+                   (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf) * h->es);
       hipError_t e = launch_convblock(h->prec, q, c.st);
       if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "convblock %s: %s", n.c_str(), hipGetErrorString(e));
     }
@@ -936,8 +942,15 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
       {"skip_conv1", BUF(c, "enc1"), h->w_sk1, h->b_sk1, d.c1, d.c2, L, BUF(c, "dec2"), "xd1"}};
   const ConvBlockW* decs[3] = {&h->dec3, &h->dec2, &h->dec1};
   const char* dn[3] = {"dec3", "dec2", "dec1"};
+  const bool fup = h->fuse && h->fuse_up && h->prec == PREC_BF16;
   for (int i = 0; i < 3; ++i) {
     const UP& u = ups[i];
+    if (fup) {   // the decoder block evaluates upsample(x) + skip_conv(h) while staging its input
+      const UpIn in{u.skip_in, u.w, u.b, u.cin, u.low};
+      h->taps.erase(std::string(u.name) + "+up");
+      conv_block(c, dn[i], *decs[i], nullptr, u.L, BUF(c, dn[i]), i == 2, nullptr, nullptr, &in);
+      continue;
+    }
     GemmParams p = gp_base(c, u.L, u.cout);   // upsample(x) + skip_conv(h)  (model.py:169-175)
     p.seg[0] = GemmSeg{u.skip_in, u.w, u.cin, 3, 0};
     p.bias0 = u.b;
@@ -1043,6 +1056,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
   if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
+  if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1374,7 +1388,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if (!graph) {
     rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipStream_t cs;

@@ -72,6 +72,10 @@ struct ConvBlockParams {
   const void* x;                      // block input [B*L, Cin]
   const float* strokes;               // enc1 only (or null): x = in_w·strokes + in_b is evaluated while staging (model.py:139)
   const float *in_w, *in_b;           // input_dense weight [Cin,2], bias [Cin]
+  // decoder blocks (or null): x = Upsample(up_low) + skip_conv(up_h) (model.py:169-175) is evaluated while staging:
+  const void* up_h; int up_cin;       //   skip-connection activation [B*L, up_cin]
+  const void* up_w; const float* up_b;   // skip_conv weight packed as a 3-tap GEMM segment [Cin x 3*up_cin], bias [Cin]
+  const void* up_low;                 //   half-resolution decoder state [B*L/2, Cin]
   int B, L, Cin, Cout;
   const void *w_c1, *w_c2, *w_fc, *w_skip;     // packed as for the GEMM kernel
   const float *b_c1, *b_c2, *b_fc, *b_skip;

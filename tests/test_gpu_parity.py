@@ -291,19 +291,21 @@ def test_one_launch_per_gemm_path_matches_reference_golden(golden_dir):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_sampler_switches_do_not_change_the_samples(prec):
-    """The all-steps text plane, the heads fused into dec1 and the enc1-fused input Linear only reorder the evaluation:
+    """The all-steps text plane, the heads fused into dec1, Upsample + skip_conv fused into the decoder blocks and the
+    enc1-fused input Linear only reorder the evaluation:
     every switch combination must give the same samples (same arithmetic per element)."""
     B, L, Lt, T = 3, 80, 9, 7
     inp = spec.synthetic_inputs(B, L, Lt, seed=12, pad=1, T=T)
     tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
     outs = {}
     for name, env in (("default", {}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
-                      ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
+                      ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
         outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
     assert torch.equal(outs["default"], outs["no_plane"])
     tol = 1e-4 if prec == "fp32" else 0.15   # fused vs unfused block kernels round intermediates at different points
     assert (outs["default"] - outs["no_fused_heads"]).abs().max().item() < tol
+    assert (outs["default"] - outs["no_fused_up"]).abs().max().item() < tol   # (bf16 only: fp32 keeps the separate GEMM)
     assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
 
 

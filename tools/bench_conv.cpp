@@ -14,8 +14,9 @@ static void* dev_rand(size_t bytes, bool f32 = false) {
 int main(int argc, char** argv) {
   const int B = 64, reps = argc > 1 ? atoi(argv[1]) : 30;
   CK(convblock_init());
-  struct Cfg { const char* n; int L, cin, cout; };
-  const Cfg cfgs[] = {{"enc1", 488, 128, 128}, {"enc2", 244, 128, 192}, {"enc4", 122, 192, 256}, {"dec3", 122, 384, 256}, {"dec2", 244, 256, 192}, {"dec1", 488, 192, 128}};
+  struct Cfg { const char* n; int L, cin, cout, up; };   // up: channels of the skip activation (fused Upsample + skip_conv input) or 0
+  const Cfg cfgs[] = {{"enc1", 488, 128, 128, 0}, {"enc2", 244, 128, 192, 0}, {"enc4", 122, 192, 256, 0}, {"dec3", 122, 384, 256, 0}, {"dec2", 244, 256, 192, 0}, {"dec1", 488, 192, 128, 0},
+                      {"dec3+up", 122, 384, 256, 256}, {"dec2+up", 244, 256, 192, 192}, {"dec1+up", 488, 192, 128, 128}};
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   unsigned long long* stamps; CK(hipMalloc(&stamps, 64 * 8));
@@ -26,6 +27,7 @@ int main(int argc, char** argv) {
     p.w_c1 = dev_rand((size_t)3 * c.cin * c.cout); p.w_c2 = dev_rand((size_t)3 * c.cout * c.cout); p.w_fc = dev_rand((size_t)2 * c.cout * c.cout); p.w_skip = dev_rand((size_t)6 * c.cin * c.cout);
     p.b_c1 = (float*)dev_rand(4096, true); p.b_c2 = p.b_c1; p.b_fc = p.b_c1; p.b_skip = p.b_c1;
     p.film = (float*)dev_rand(1 << 20, true); p.film_bs = 0; p.film_tot = 9280; p.f1 = 0; p.f2 = 256; p.f3 = 512;
+    if (c.up) { p.up_h = dev_rand(rows * c.up * 2); p.up_cin = c.up; p.up_w = dev_rand((size_t)6 * c.up * c.cin); p.up_b = p.b_c1; p.up_low = p.x; }
     p.out = dev_rand(rows * c.cout * 2); p.out_f32 = 0; p.pool = nullptr; p.stamps = stamps;
     CK(hipMemset(stamps, 0, 64 * 8));
     for (int i = 0; i < 3; ++i) CK(launch_convblock(PREC_BF16, p, st));
