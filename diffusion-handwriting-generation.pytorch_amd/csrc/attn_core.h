@@ -184,22 +184,19 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
 
 // cooperative copy of one key block into LDS: K rows [kb, kb+KB) x C channels from `ksrc` (row stride ldk elements,
 // already offset to the sample's first key row and first K channel) and V^T rows [0,C) x keys [kb, kb+KB) from `vsrc`
-// ([C][lpad], offset to the sample).  Keys past `krows` (rows the buffer really holds for this sample + slack) are
-// still read (finite slack / neighbour rows) and masked by the caller; V^T keys past lpad are zero-filled.
+// ([C][lpad], offset to the sample).  K rows at or past `kmax` (the sample's key count) and V^T keys past lpad are
+// zero-filled, never read.
 template <typename T, int KB>
 DHW_DEV void attn_stage_kv(char* kt, int SK, char* vt, int SV, const T* ksrc, int ldk, const T* vsrc, int lpad, int C,
-                           int kb, int tid, int nthreads) {
-  constexpr int ES = sizeof(T), EPV = 16 / ES;
-  const int cpr = C / EPV;            // 16-byte pieces per K row
-  for (int id = tid; id < KB * cpr; id += nthreads) {
-    const int r = id / cpr, cc = id - r * cpr;
-    *reinterpret_cast<uint4*>(kt + r * SK + cc * 16) = *reinterpret_cast<const uint4*>(ksrc + (size_t)(kb + r) * ldk + cc * EPV);
-  }
-  constexpr int PPR = KB / EPV;       // 16-byte pieces per V^T row
-  for (int id = tid; id < C * PPR; id += nthreads) {
-    const int ch = id / PPR, part = id - ch * PPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (kb + (part + 1) * EPV <= lpad) v = *reinterpret_cast<const uint4*>(vsrc + (size_t)ch * lpad + kb + part * EPV);
-    *reinterpret_cast<uint4*>(vt + ch * SV + part * 16) = v;
-  }
+                           int kb, int kmax, int tid, int nthreads) {
+  constexpr int ES = sizeof(T), EPV = 16 / ES, PPR = KB / EPV;
+  const int cpr = C / EPV;            // 16-byte pieces per K row; PPR = pieces per V^T row
+  staged_copy<6>(KB * cpr, tid, nthreads,
+      [&](int id) { const int r = id / cpr, cc = id - r * cpr;
+                    return kb + r < kmax ? reinterpret_cast<const uint4*>(ksrc + (size_t)(kb + r) * ldk + cc * EPV) : nullptr; },
+      [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(kt + r * SK + cc * 16); });
+  staged_copy<6>(C * PPR, tid, nthreads,
+      [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                    return kb + (part + 1) * EPV <= lpad ? reinterpret_cast<const uint4*>(vsrc + (size_t)ch * lpad + kb + part * EPV) : nullptr; },
+      [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(vt + ch * SV + part * 16); });
 }

@@ -115,25 +115,17 @@ void convblock_kernel(const ConvBlockParams p) {
       epu.load(p.up_b, nullptr, nullptr, nu);
     }
     {
-      const int cpr = Ch * ES / 16;
+      const int cpr = Ch * ES / 16, cpx = Cin * ES / 16;
       const char* src = reinterpret_cast<const char*>(p.up_h);
-      for (int id = tid; id < RH * cpr; id += NTHR) {
-        const int r = id / cpr, cc = id - r * cpr;
-        const int lrow = m0 - 3 + r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lrow >= 0 && lrow < p.L) v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Ch) * ES + (size_t)cc * 16);
-        *reinterpret_cast<uint4*>(HS + r * SHh + cc * 16) = v;
-      }
-      const int cpx = Cin * ES / 16;
       const char* low = reinterpret_cast<const char*>(p.up_low);
-      for (int id = tid; id < RX * cpx; id += NTHR) {
-        const int r = id / cpx, cc = id - r * cpx;
-        const int lrow = m0 - 2 + r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lrow >= 0 && lrow < p.L)
-          v = *reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * Cin) * ES + (size_t)cc * 16);
-        *reinterpret_cast<uint4*>(XR + r * SX + cc * 16) = v;
-      }
+      staged_copy<4>(RH * cpr, tid, NTHR,
+          [&](int id) { const int r = id / cpr, cc = id - r * cpr, lrow = m0 - 3 + r;
+                        return lrow >= 0 && lrow < p.L ? reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Ch) * ES + (size_t)cc * 16) : nullptr; },
+          [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(HS + r * SHh + cc * 16); });
+      staged_copy<4>(RX * cpx, tid, NTHR,
+          [&](int id) { const int r = id / cpx, cc = id - r * cpx, lrow = m0 - 2 + r;
+                        return lrow >= 0 && lrow < p.L ? reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * Cin) * ES + (size_t)cc * 16) : nullptr; },
+          [&](int id) { const int r = id / cpx, cc = id - r * cpx; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); });
     }
     lds_barrier();
     f32x4 acc[NTU][MTU];

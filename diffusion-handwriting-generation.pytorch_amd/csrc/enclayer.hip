@@ -12,6 +12,7 @@
 // (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
 #include "attn_core.h"
 #include "gemm_core.h"
+#include <algorithm>
 #include <cstdlib>
 #include "dhw_kernels.h"
 
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int l15 = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles = (p.Lk + BM - 1) / BM;
-  const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one sample run on one XCD (shared K/V in its L2)
+  const int b = bid / tiles, m0 = (bid % tiles) * BM;
   const int S = tile_stride<T>(DM);
   char* XR = smem;               // x, later x2
   char* QR = XR + BM * S;        // q1, later a1
@@ -92,6 +94,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
   ep.load(p.b_q1, nullptr, nullptr, n0);
   stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
+  // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
+  constexpr int KBC = 32, SKC = DM * ES + 16, SVC = KBC * ES + 16;
+  char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+  char* VT = KT + KBC * SKC;
+  const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
+  const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
+  attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
   lds_barrier();
   STAMP(1);
 
@@ -117,10 +126,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   STAMP(2);
 
   {  // ---- cross attention over the Lt text keys (K/V staged in LDS, 32 keys per block); a1 overwrites q1 in place
-    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBC = 32;
-    constexpr int SK = DM * ES + 16, SV = KBC * ES + 16;
-    char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
-    char* VT = KT + KBC * SK;
+    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS;
+    constexpr int SK = SKC, SV = SVC;
     const int rg = wave % RG, hs = wave / RG;
     Frag<T> qf[UMAX][2];
     float mr[UMAX], lr[UMAX];
@@ -138,9 +145,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
     for (int kb = 0; kb < p.Lt; kb += KBC) {
-      attn_stage_kv<T, KBC>(KT, SK, VT, SV, reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM, DM,
-                            reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT, p.lpadT, DM, kb, tid, 512);
-      lds_barrier();
+      if (kb) {
+        attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
+        lds_barrier();
+      }
 #pragma unroll
       for (int u = 0; u < UMAX; ++u) {
         const int h = hs + u * HS;
@@ -216,6 +224,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ring.template run<MT>(acc, xop + opaque, S, KC);
     STAMP(12 + chunk);
     if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
+    if (chunk < 2 && MT == 1) {
+      // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
+      const int r = m0 + row0 + l15;
+      if (r < p.Lk) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
+      }
+      STAMP(5 + chunk);
+      continue;
+    }
     lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V) is free: every wave is past its readers
     if (chunk < 2) {
       // q2 / k2 chunk -> LDS tile [row][DM] -> coalesced rows of qk2 [.., 2*DM]
@@ -253,6 +272,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// keys per staged self-attention block: 128 when K [keys][DM] + V^T [DM][keys] fit beside the a2 tile (they overlay the
+// x3 / FFN tiles, which are written only after the attention), else 64
+template <typename T, int DM, int BM>
+constexpr int self_kbs() {
+  return (size_t)BM * (DM * sizeof(T) + 16) + (size_t)128 * (DM * sizeof(T) + 16) + (size_t)DM * (128 * sizeof(T) + 16) <= 160 * 1024 ? 128 : 64;
+}
+template <typename T, int DM, int BM>
+constexpr size_t lds_bc_bytes() {
+  constexpr size_t S = DM * sizeof(T) + 16, KBS = self_kbs<T, DM, BM>();
+  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = BM * S + KBS * S + DM * (KBS * sizeof(T) + 16);
+  return stages > att ? stages : att;
+}
+
 template <typename T, int DM, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p) {
   constexpr int ES = sizeof(T);
@@ -264,7 +296,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int l15 = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles = (p.Lk + BM - 1) / BM;
-  const int b = blockIdx.x / tiles, m0 = (blockIdx.x % tiles) * BM;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one sample run on one XCD (shared K/V in its L2)
+  const int b = bid / tiles, m0 = (bid % tiles) * BM;
   const int S = tile_stride<T>(DM);
   char* R1 = smem;               // a2, later SiLU(x3)
   char* R2 = R1 + BM * S;        // x3
@@ -283,9 +316,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   STAMP(16);
   if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[40] = __builtin_amdgcn_s_memtime();
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
-    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = 64;
+    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
     constexpr int SK = DM * ES + 16, SV = KBS * ES + 16;
-    char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    char* KT = R2;
     char* VT = KT + KBS * SK;
     const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
@@ -305,15 +338,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     for (int kb = 0; kb < p.Lk; kb += KBS) {
       attn_stage_kv<T, KBS>(KT, SK, VT, SV, qk + (size_t)b * p.Lk * 2 * DM + DM, 2 * DM,
-                            reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX, p.lpadX, DM, kb, tid, 512);
+                            reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX, p.lpadX, DM, kb, p.Lk, tid, 512);
       lds_barrier();
+      if (kb < 3 * KBS) STAMP(26 + 2 * (kb / KBS));
 #pragma unroll
       for (int u = 0; u < UMAX; ++u) {
         const int h = hs + u * HS;
-        if (h < H)
-          attn_block_lds<T, 64, KBS>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb,
-                                     nullptr, p.Lk, mr[u], lr[u], o[u]);
+        if (h < H) {
+#pragma unroll
+          for (int sub = 0; sub < KBS; sub += 64)
+            if (kb + sub < p.Lk)
+              attn_block_lds<T, 64, 64>(qf[u], KT + (sub + l15) * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + (sub + 4 * g) * ES, SV,
+                                        kb + sub, nullptr, p.Lk, mr[u], lr[u], o[u]);
+        }
       }
+      if (kb < 3 * KBS) STAMP(27 + 2 * (kb / KBS));
       lds_barrier();   // the staging tiles are rewritten by the next block
     }
 #pragma unroll
@@ -429,7 +468,7 @@ hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
     const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red + (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16);
     hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   } else {
-    const size_t lds = (size_t)3 * BM * tile_stride<T>(DM) + red + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16);
+    const size_t lds = lds_bc_bytes<T, DM, BM>();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((enc_bc_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
   }
@@ -456,8 +495,11 @@ hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st) {
   if ((long)p.B * ((p.Lk + 63) / 64) < target) bm = 32;
   if (DM % 128 == 0 && (long)p.B * ((p.Lk + 31) / 32) < target) bm = 16;   // (the 4x2 wave layout of DM=192 needs >= 32 rows)
   if (force) bm = force;
-  // LDS budget (160 KiB): 3 row tiles + K/V staging in enc_bc; shrink the row tile until it fits
-  auto lds_bc = [](int m) { return (size_t)3 * m * tile_stride<T>(DM) + 2 * 8 * m * sizeof(float) + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16); };
+  // LDS budget (160 KiB) of enc_bc: the three stage tiles, or the a2 tile + one 64-key K/V block; shrink the row tile until it fits
+  auto lds_bc = [](int m) {
+    return std::max((size_t)3 * m * tile_stride<T>(DM) + 2 * 8 * m * sizeof(float),
+                    (size_t)m * tile_stride<T>(DM) + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16));
+  };
   while (bm > 16 && lds_bc(bm) > 160 * 1024) bm /= 2;
   if (DM % 128 != 0 && bm < 32) bm = 32;
   if (bm == 16) return launch_pair<T, DM, (DM % 128 == 0 ? 16 : 32)>(p, which, st);

@@ -54,6 +54,34 @@ int main(int argc, char** argv) {
     p.x2 = dev_rand(rows * d * 2); p.qk2 = dev_rand(rows * 2 * d * 2); p.vt2 = dev_rand((size_t)(B * d + 128) * lpadX * 2); p.lpadX = lpadX;
     p.out = dev_rand(rows * d * 2); p.pool = nullptr;
     p.stamps = stamps;
+    {  // realistic order: enc_a writes qk2 / vt2 / x2, enc_bc reads them straight after (timed per launch with events)
+      p.dbg = 0; p.stamps = stamps;
+      CK(hipMemset(stamps, 0, 64 * 8));
+      hipEvent_t ev[3];
+      for (auto& evt : ev) CK(hipEventCreate(&evt));
+      double ta = 0, tb = 0;
+      for (int i = 0; i < reps + 3; ++i) {
+        CK(hipEventRecord(ev[0], st));
+        CK(launch_enclayer(PREC_BF16, p, 0, st));
+        CK(hipEventRecord(ev[1], st));
+        CK(launch_enclayer(PREC_BF16, p, 1, st));
+        CK(hipEventRecord(ev[2], st));
+        CK(hipEventSynchronize(ev[2]));
+        float a, bms;
+        CK(hipEventElapsedTime(&a, ev[0], ev[1])); CK(hipEventElapsedTime(&bms, ev[1], ev[2]));
+        if (i >= 3) { ta += a; tb += bms; }
+      }
+      printf("pair  d=%d Lk=%d: enc_a %.2f us, enc_bc %.2f us (alternating launches, event-timed)\n", d, Lk, ta * 1e3 / reps, tb * 1e3 / reps);
+      unsigned long long hs[64];
+      CK(hipMemcpy(hs, stamps, sizeof hs, hipMemcpyDeviceToHost));
+      printf("      enc_bc WG0 in the pair [us]: att blocks (staged, computed):");
+      for (int k = 26; k < 32; ++k) printf(" %.2f", hs[k] ? (double)(hs[k] - hs[16]) / 100.0 : -1.0);
+      printf(" | stages:");
+      for (int k = 17; k <= 24; ++k) printf(" %.2f", (double)(hs[k] - hs[16]) / 100.0);
+      printf("\n      enc_a WG0 in the pair [us]:");
+      for (int k = 1; k <= 14; ++k) printf(" %.2f", (double)(hs[k] - hs[0]) / 100.0);
+      printf("\n");
+    }
     for (int dbg = 0; dbg < 2; ++dbg)
     for (int which = dbg; which < 2; ++which) {
       p.dbg = dbg;
