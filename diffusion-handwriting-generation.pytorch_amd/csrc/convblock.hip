@@ -128,9 +128,11 @@ void convblock_kernel(const ConvBlockParams p) {
           [&](int id) { const int r = id / cpx, cc = id - r * cpx; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); });
     }
     lds_barrier();
+    STAMP(10);
     f32x4 acc[NTU][MTU];
     acc_zero(acc);
     if (actu) ringu.template run<MTU>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
+    STAMP(11);
     if (act1) {
       ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during the epilogue
       ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
@@ -155,6 +157,7 @@ void convblock_kernel(const ConvBlockParams p) {
           }
         }
     }
+    STAMP(12);
     lds_barrier();   // HS (aliasing h1) is rewritten just below
   } else if (p.strokes) {
     // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load
@@ -369,9 +372,18 @@ hipError_t convblock_init() {
   if ((e = attr<bf16_t, 128, 128, 8, 1, 192>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8, 1, 256>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8, 1, 384>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 48, 256, 8, 1, 384>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 48, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
   return attr<float, 32, 256, 4>();
+}
+
+// 46-row tiles for the widest blocks (L/4 level) when the 62-row tiling leaves CUs idle and the finer one still fits one round
+static bool use_bm48(const ConvBlockParams& p) {
+  if (const char* e = getenv("DHW_CONV_BM")) return atoi(e) == 48;
+  const long t64 = (long)p.B * ((p.L + 61) / 62), t48 = (long)p.B * ((p.L + 45) / 46);
+  return t64 < 256 && t48 <= 256 && t48 > t64;
 }
 
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) {
@@ -383,7 +395,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
       return big ? launch_t<bf16_t, 128, 128, 8, 1, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192>(p, st);
     }
     if (p.Cout == 192 && p.Cin == 256) return launch_t<bf16_t, 64, 192, 8, 1, 256>(p, st);
-    if (p.Cout == 256 && p.Cin == 384) return launch_t<bf16_t, 64, 256, 8, 1, 384>(p, st);
+    if (p.Cout == 256 && p.Cin == 384) return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 384>(p, st) : launch_t<bf16_t, 64, 256, 8, 1, 384>(p, st);
     return hipErrorInvalidValue;
   }
   if (prec == PREC_BF16) {
@@ -400,6 +412,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
           return launch_t<bf16_t, 64, 192, 8, 2>(p, st);
         return launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
+        if (use_bm48(p)) return launch_t<bf16_t, 48, 256, 8>(p, st);
         return (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) ? launch_t<bf16_t, 32, 256, 8>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);
     }
   } else {

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     printf("%s L=%d %d->%d: %.2f us/launch (%d WGs); WG0 stamps [us]: stage0 %.2f | s1 run %.2f epi+bar %.2f | s2 run %.2f epi+bar %.2f | fc %.2f skip %.2f | bar %.2f out %.2f\n",
            c.n, c.L, c.cin, c.cout, ms * 1e3 / reps, B * ((c.L + 61) / 62),
            (h[1]-h[0])/100.0, (h[2]-h[1])/100.0, (h[3]-h[2])/100.0, (h[4]-h[3])/100.0, (h[5]-h[4])/100.0, (h[6]-h[5])/100.0, (h[7]-h[6])/100.0, (h[8]-h[7])/100.0, (h[9]-h[8])/100.0);
+    if (c.up) printf("    fused input stage: staged %.2f | skip_conv run %.2f | epilogue %.2f | barrier+tail %.2f\n", (h[10]-h[0])/100.0, (h[11]-h[10])/100.0, (h[12]-h[11])/100.0, (h[1]-h[12])/100.0);
   }
   return 0;
 }
