@@ -200,6 +200,7 @@ struct dhw_handle {
   bool fuse_heads = true;       // dec1 evaluates heads + scheduler step (env DHW_FUSE_HEADS=0 -> separate launch)
   bool plane = true;            // all-steps text plane in dhw_sample (env DHW_PLANE=0 -> text side inside every step)
   bool fuse_up = true;          // decoder ConvBlocks evaluate Upsample + skip_conv while staging (env DHW_FUSE_UP=0 -> separate GEMM)
+  bool chain = true;            // row-local stages continue across layer boundaries inside one launch (env DHW_CHAIN=0 -> off)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
@@ -689,8 +690,9 @@ void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
   }
 }
 
-void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
-               void* pool) {
+// parameters of the fused EncoderLayer kernels for layer n (x may be null when the tile is handed over in LDS)
+EncLayerParams enc_params(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
+                          void* pool) {
   dhw_handle* h = c.h;
   const int d = w.d;
   // text keys/values of this layer: per-call buffers, or step `plane_step` of the all-steps plane
@@ -700,24 +702,47 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
     k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
     vt1p += (size_t)c.plane_step * c.B * d * h->lpadT * h->es;
   }
+  EncLayerParams q{};
+  q.B = c.B; q.Lk = Lk; q.Lt = c.Lt; q.d = d; q.heads = w.heads;
+  q.x = x;
+  q.w_q1 = w.w_q1; q.w_d1 = w.w_d1; q.w_qkv2 = w.w_qkv2; q.w_d2 = w.w_d2; q.w_f1 = w.w_f1; q.w_f2 = w.w_f2;
+  q.b_q1 = w.b_q1; q.b_d1 = w.b_d1; q.b_qkv2 = w.b_qkv2; q.b_d2 = w.b_d2; q.b_f1 = w.b_f1; q.b_f2 = w.b_f2;
+  q.pb_q1 = w.pb_q1; q.pb_qk2 = w.pb_qk2;
+  q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot; q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
+  q.k1 = k1p; q.vt1 = vt1p; q.lpadT = h->lpadT; q.text = text;
+  q.x2 = BUF(c, n + ".x2"); q.qk2 = BUF(c, n + ".qk2"); q.vt2 = BUF(c, n + ".vt2"); q.lpadX = lpad;
+  q.out = BUF(c, n); q.pool = pool;
+  return q;
+}
+
+// skip_a: this layer's enc_a half was already evaluated by the previous launch (EncChain); chain: what this layer's
+// enc_bc launch continues with (or null)
+void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
+               void* pool, bool skip_a = false, const EncChain* chain = nullptr, int bm_min = 0) {
+  dhw_handle* h = c.h;
+  const int d = w.d;
+  const char* k1p = (const char*)BUF(c, n + (c.use_plane ? ".k1.T" : ".k1"));
+  const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
+  if (c.use_plane) {
+    k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
+    vt1p += (size_t)c.plane_step * c.B * d * h->lpadT * h->es;
+  }
   if (h->fuse && enclayer_supported(h->prec, d, w.heads)) {
-    EncLayerParams q{};
-    q.B = c.B; q.Lk = Lk; q.Lt = c.Lt; q.d = d; q.heads = w.heads;
-    q.x = x;
-    q.w_q1 = w.w_q1; q.w_d1 = w.w_d1; q.w_qkv2 = w.w_qkv2; q.w_d2 = w.w_d2; q.w_f1 = w.w_f1; q.w_f2 = w.w_f2;
-    q.b_q1 = w.b_q1; q.b_d1 = w.b_d1; q.b_qkv2 = w.b_qkv2; q.b_d2 = w.b_d2; q.b_f1 = w.b_f1; q.b_f2 = w.b_f2;
-    q.pb_q1 = w.pb_q1; q.pb_qk2 = w.pb_qk2;
-    q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot; q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
-    q.k1 = k1p; q.vt1 = vt1p; q.lpadT = h->lpadT; q.text = text;
-    q.x2 = BUF(c, n + ".x2"); q.qk2 = BUF(c, n + ".qk2"); q.vt2 = BUF(c, n + ".vt2"); q.lpadX = lpad;
-    q.out = BUF(c, n); q.pool = pool;
+    EncLayerParams q = enc_params(c, n, w, x, Lk, lpad, text, pool);
+    q.bm_min = bm_min;
     const double rows = (double)c.B * Lk, dd = d;
-    for (int which = 0; which < 2 && !c.err; ++which) {
-      const double fl = which == 0 ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd
-                                   : 2.0 * rows * dd * dd * 5 + 4.0 * rows * Lk * dd;
-      const double by = (which == 0 ? rows * dd * 5 : rows * dd * (5 + (pool ? 0.5 : 0.0))) * h->es + 5.0 * dd * dd * h->es;
-      Launch l(h, c.st, which == 0 ? "enc.fused_a" : "enc.fused_bc", fl, by);
-      hipError_t e = launch_enclayer(h->prec, q, which, c.st);
+    for (int which = skip_a ? 1 : 0; which < 2 && !c.err; ++which) {
+      double fl = which == 0 ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd
+                             : 2.0 * rows * dd * dd * 5 + 4.0 * rows * Lk * dd;
+      double by = (which == 0 ? rows * dd * 5 : rows * dd * (5 + (pool ? 0.5 : 0.0))) * h->es + 5.0 * dd * dd * h->es;
+      const EncChain* ch = which == 1 ? chain : nullptr;
+      if (ch && ch->mode) {   // + the chained layer's enc_a (+ att_dense)
+        const double r2 = (double)c.B * ch->a.Lk, d2 = ch->a.d;
+        fl += 2.0 * r2 * d2 * d2 * 5 + 4.0 * r2 * c.Lt * d2 + (ch->mode == 2 ? 2.0 * r2 * dd * d2 : 0.0);
+        by += r2 * d2 * 5 * h->es + 5.0 * d2 * d2 * h->es;
+      }
+      Launch l(h, c.st, which == 0 ? "enc.fused_a" : (ch && ch->mode ? "enc.fused_bc+a" : "enc.fused_bc"), fl, by);
+      hipError_t e = launch_enclayer(h->prec, q, which, c.st, ch);
       if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "enclayer %s/%d: %s", n.c_str(), which, hipGetErrorString(e));
     }
     tap(c, n + ".x2", n + ".x2", Lk, d);
@@ -920,19 +945,38 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr);
   enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"));
   conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr);
-  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"));
-  {
+  // Everything between two self-attentions is row-local, so enc5's second half continues into AvgPool + att_dense + the
+  // first attention layer's first half, and every attention layer's second half into the next layer's first half.
+  const bool chain_ok = h->fuse && h->chain && h->prec == PREC_BF16;
+  const int nl = d.num_layers;
+  auto att_name = [](int i) { return "att_layers." + std::to_string(i); };
+  EncChain ch5{};
+  if (chain_ok && nl > 0 && enclayer_supported(h->prec, dt, h->el[2].heads) && enclayer_chain_supported(h->prec, d.c3, c.B, L / 4, 2, dt)) {
+    ch5.mode = 2;
+    ch5.a = enc_params(c, att_name(0), h->el[2], nullptr, L / 8, h->lpadX[2], text, nullptr);
+    ch5.w_dense = h->w_attd; ch5.b_dense = h->b_attd; ch5.dense_out = BUF(c, "att_dense");
+  }
+  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"), false, ch5.mode ? &ch5 : nullptr,
+            ch5.mode ? 32 : 0);
+  if (!ch5.mode) {
     GemmParams p = gp_base(c, L / 8, dt);
     p.seg[0] = GemmSeg{BUF(c, "enc5.pool"), h->w_attd, d.c3, 1, 0};
     p.bias0 = h->b_attd;
     p.out = BUF(c, "att_dense");
     run_gemm(c, "att_dense", p);
-    tap(c, "att_dense", "att_dense", L / 8, dt);
   }
+  tap(c, "att_dense", "att_dense", L / 8, dt);
   const void* x = BUF(c, "att_dense");
-  for (int i = 0; i < d.num_layers; ++i) {
-    const std::string n = "att_layers." + std::to_string(i);
-    enc_layer(c, n, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr);
+  bool a_done = ch5.mode != 0;   // this layer's first half was evaluated by the previous launch
+  for (int i = 0; i < nl; ++i) {
+    const std::string n = att_name(i);
+    EncChain chn{};
+    if (chain_ok && i + 1 < nl && enclayer_chain_supported(h->prec, dt, c.B, L / 8, 1, dt)) {
+      chn.mode = 1;
+      chn.a = enc_params(c, att_name(i + 1), h->el[3 + i], nullptr, L / 8, h->lpadX[2], text, nullptr);
+    }
+    enc_layer(c, n, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr, a_done, chn.mode ? &chn : nullptr);
+    a_done = chn.mode != 0;
     x = BUF(c, n);
   }
   struct UP { const char* name; const void* skip_in; void* w; float* b; int cin, cout, L; const void* low; const char* out; };
@@ -1057,6 +1101,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
+  if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1388,7 +1433,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if (!graph) {
     rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
       hipStream_t cs;

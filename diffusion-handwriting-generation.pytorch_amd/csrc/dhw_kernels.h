@@ -103,11 +103,24 @@ struct EncLayerParams {
   void* x2;                                        // [B*Lk, d]     written by enc_a, read by enc_bc
   void* qk2; void* vt2; int lpadX;                 // [B*Lk, 2d], [B][d][lpadX]
   void* out; void* pool;                           // [B*Lk, d], optional [B*Lk/2, d]
+  int bm_min;                                      // 0, or the smallest row tile to use (32 when enc_bc chains into a pooled layer)
   int dbg;                                         // diagnostics only: bit0 = skip the attention stage (a = q)
   unsigned long long* stamps;                      // diagnostics only: per-stage s_memrealtime of workgroup 0 (16 slots per kernel) or null
 };
+// What an enc_bc (or ConvBlock) workgroup goes on to compute for its own rows after its own block — the stages up to the
+// next self-attention are row-local, so they need no launch boundary:
+//   mode 1: enc_a of the next EncoderLayer on the block's output tile (same width);
+//   mode 2: AvgPool1d(2) -> Linear (att_dense, model.py:160-162) -> enc_a of the first attention layer.
+struct EncChain {
+  int mode;                  // 0 = none
+  EncLayerParams a;          // the next layer (a.x unused: the tile is already in LDS)
+  const void* w_dense; const float* b_dense;   // mode 2: packed weight [a.d x d], bias [a.d]
+  void* dense_out;           // mode 2: Linear output [B*Lk/2, a.d] (kept for debug taps)
+};
 bool enclayer_supported(int prec, int d, int heads);
-hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st);
+// whether enc_bc of a (d, B, Lk) layer can continue with `mode`; mode 2 needs EncLayerParams.bm_min = 32 on that layer
+bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_next);
+hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain = nullptr);
 hipError_t enclayer_init();
 
 // ---------------------------------------------------------------- attention

@@ -64,22 +64,35 @@ struct EpiParams {
   }
 };
 
+// LDS regions of the enc_a stages.  XR and QR are [BM][DM] tiles (row stride tile_stride(DM)); VS is the staging area of the
+// transposed v2 tile (DM rows of BM keys), free to overlay XR / QR; KT / VT hold one 32-key block of text keys / values.
+struct EncALds {
+  char* XR;     // x, later x2
+  char* QR;     // q1, later a1
+  float* red;   // LayerNorm partial sums [2][8][BM]
+  char* KT;
+  char* VT;
+  char* VS;
+};
 template <typename T, int DM, int BM>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {
+constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16); }
+
+// enc_a for the BM-row tile [m0, m0+BM) of sample b, of which the first rows_valid rows are this workgroup's to write.
+// p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
+// ConvBlock or the previous layer's enc_bc continues into the next layer without a launch boundary.  VPIECE = bytes per
+// store of the transposed v2 tile (16, or 4 when m0 is only even).
+template <typename T, int DM, int BM, int VPIECE = 16>
+DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0, int rows_valid) {
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
-  const int tiles = (p.Lk + BM - 1) / BM;
-  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one sample run on one XCD (shared K/V in its L2)
-  const int b = bid / tiles, m0 = (bid % tiles) * BM;
   const int S = tile_stride<T>(DM);
-  char* XR = smem;               // x, later x2
-  char* QR = XR + BM * S;        // q1, later a1
-  float* red = reinterpret_cast<float*>(QR + BM * S);
+  char* XR = m.XR;
+  char* QR = m.QR;
+  float* red = m.red;
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
   const int row0 = wm * (BM / WM), ntile0 = wn * NT;
@@ -93,11 +106,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   STAMP(0);
   ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
   ep.load(p.b_q1, nullptr, nullptr, n0);
-  stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
+  if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
   // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
   constexpr int KBC = 32, SKC = DM * ES + 16, SVC = KBC * ES + 16;
-  char* KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
-  char* VT = KT + KBC * SKC;
+  char* KT = m.KT;
+  char* VT = m.VT;
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
   attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
@@ -201,7 +214,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   lds_barrier();
   STAMP(4);
-  const int rows_valid = min(BM, p.Lk - m0);
   tile_copy_out<T>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
 
   // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
@@ -226,11 +238,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
     if (chunk < 2 && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
-      const int r = m0 + row0 + l15;
-      if (r < p.Lk) {
+      const int r = row0 + l15;
+      if (r < rows_valid) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
+          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
       }
       STAMP(5 + chunk);
       continue;
@@ -246,9 +258,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       lds_barrier();
       tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * 2 * DM + chunk * DM, 2 * DM, rows_valid, DM, tid, 512);
     } else {
-      // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past Lk) -> coalesced 128-byte rows of vt2
+      // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2
       constexpr int SV = BM * ES + 16;
-      char* VT = smem;   // spans the x2 and q1 regions: DM * SV <= 2 * BM * S
+      char* VS = m.VS;
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -257,19 +269,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const f32x4 v = acc[i][j] + ep.bias[i];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<T*>(VT + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(m0 + rl < p.Lk ? v[k] : 0.f);
+            *reinterpret_cast<T*>(VS + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(rl < rows_valid ? v[k] : 0.f);
         }
       lds_barrier();
-      constexpr int EPV = 16 / ES, PPR = BM / EPV;   // 16-byte pieces per channel row
+      // keys this tile owns: its valid rows; the sample's last tile also zero-fills the padding up to lpadX
+      constexpr int KPP = VPIECE / ES, PPR = BM / KPP;   // keys per piece, pieces per channel row
+      const int klimit = m0 + rows_valid >= p.Lk ? min(BM, p.lpadX - m0) : rows_valid;
       for (int id = tid; id < DM * PPR; id += 512) {
         const int ch = id / PPR, part = id - ch * PPR;
-        if (m0 + (part + 1) * EPV <= p.lpadX)
-          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + ch) * p.lpadX + m0 + part * EPV) =
-              *reinterpret_cast<const uint4*>(VT + ch * SV + part * 16);
+        if ((part + 1) * KPP <= klimit) {
+          T* dst = reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + ch) * p.lpadX + m0 + part * KPP;
+          const char* src = VS + ch * SV + part * VPIECE;
+          if constexpr (VPIECE == 16) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+          else *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+        }
       }
     }
     STAMP(5 + chunk);
   }
+}
+
+template <typename T, int DM, int BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles = (p.Lk + BM - 1) / BM;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one sample run on one XCD (shared K/V in its L2)
+  const int b = bid / tiles, m0 = (bid % tiles) * BM;
+  const int S = tile_stride<T>(DM);
+  EncALds m;
+  m.XR = smem;
+  m.QR = m.XR + BM * S;
+  m.red = reinterpret_cast<float*>(m.QR + BM * S);
+  m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
+  m.VT = m.KT + 32 * (DM * sizeof(T) + 16);
+  m.VS = smem;   // spans the x2 and q1 tiles: DM * (BM * ES + 16) <= 2 * BM * S
+  enc_a_body<T, DM, BM>(p, m, b, m0, min(BM, p.Lk - m0));
 }
 
 // keys per staged self-attention block: 128 when K [keys][DM] + V^T [DM][keys] fit beside the a2 tile (they overlay the
@@ -285,8 +319,16 @@ constexpr size_t lds_bc_bytes() {
   return stages > att ? stages : att;
 }
 
-template <typename T, int DM, int BM>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p) {
+// NEXT: 0, or the EncChain mode compiled into this variant (DN = width of the chained layer)
+template <typename T, int DM, int BM, int NEXT>
+constexpr size_t lds_bc_chain_bytes() {
+  constexpr size_t S = DM * sizeof(T) + 16, base = 3 * BM * S + 2 * 8 * BM * sizeof(float);
+  constexpr size_t chain = NEXT == 1 ? base + enc_a_text_kv_bytes<T, DM, BM>() : NEXT == 2 ? base + enc_a_text_kv_bytes<T, 384, BM / 2>() : 0;
+  return chain > lds_bc_bytes<T, DM, BM>() ? chain : lds_bc_bytes<T, DM, BM>();
+}
+
+template <typename T, int DM, int BM, int NEXT = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p, const EncChain nx) {
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
@@ -458,21 +500,101 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);
   if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[41] = __builtin_amdgcn_s_memtime();
+
+  if constexpr (NEXT == 1) {
+    // the next layer's enc_a on the out tile (R3): q1 / a1 in R1, the v2 staging area over R1..R2 (both dead by now)
+    EncALds m;
+    m.XR = R3; m.QR = R1; m.red = red;
+    m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    m.VT = m.KT + 32 * (DM * ES + 16);
+    m.VS = R1;
+    enc_a_body<T, DM, BM>(nx.a, m, b, m0, rows_valid);
+  } else if constexpr (NEXT == 2) {
+    // AvgPool1d(2) of the out tile -> R1; Linear DM -> DN (att_dense) -> x tile of the first attention layer; its enc_a
+    constexpr int DN = 384, BN2 = BM / 2, SN = DN * ES + 16, NTN = DN / 8 / 16, MTN = BN2 / 16;
+    {
+      constexpr int EPV = 16 / ES;
+      const int cpr = DM / EPV;
+      for (int id = tid; id < BN2 * cpr; id += 512) {
+        const int r = id / cpr, cc = id - r * cpr;
+        uint4 a = *reinterpret_cast<const uint4*>(R3 + (2 * r) * S + cc * 16);
+        const uint4 bq = *reinterpret_cast<const uint4*>(R3 + (2 * r + 1) * S + cc * 16);
+        T* ea = reinterpret_cast<T*>(&a);
+        const T* eb = reinterpret_cast<const T*>(&bq);
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) ea[k] = from_f<T>(0.5f * (to_f(ea[k]) + to_f(eb[k])));
+        *reinterpret_cast<uint4*>(R1 + r * S + cc * 16) = a;
+      }
+    }
+    WRing<T, NTN> rd;
+    EpiParams<NTN> epd;
+    const int nt0 = wave * NTN, nn0 = nt0 * 16 + 4 * g;
+    rd.fill(reinterpret_cast<const T*>(nx.w_dense) + ((size_t)nt0 * KC * 64 + lane) * 8, KC);
+    epd.load(nx.b_dense, nullptr, nullptr, nn0);
+    lds_barrier();   // pooled tile complete; every read of the out tile (copy-out, pooling) is done
+    char* XN = R2;   // x tile of the chained layer, then its q1 tile: together BM * SN <= 2 * BM * S bytes over R2..R3
+    {
+      f32x4 acc[NTN][MTN];
+      acc_zero(acc);
+      rd.template run<MTN>(acc, R1 + l15 * S + g * 8 * ES, S, KC);
+#pragma unroll
+      for (int i = 0; i < NTN; ++i)
+#pragma unroll
+        for (int j = 0; j < MTN; ++j)
+          store4(reinterpret_cast<T*>(XN + (j * 16 + l15) * SN) + nn0 + 16 * i, acc[i][j] + epd.bias[i]);
+    }
+    lds_barrier();
+    const int m02 = m0 / 2, rows2 = rows_valid / 2;
+    tile_copy_out<T>(XN, SN, reinterpret_cast<T*>(nx.dense_out) + (size_t)(b * (p.Lk / 2) + m02) * DN, DN, rows2, DN, tid, 512);
+    EncALds m;
+    m.XR = XN; m.QR = XN + BN2 * SN; m.red = red;
+    m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    m.VT = m.KT + 32 * (DN * ES + 16);
+    m.VS = XN;
+    enc_a_body<T, DN, BN2>(nx.a, m, b, m02, rows2);
+  }
+}
+
+template <typename T, int DM, int BM, int NEXT = 0>
+hipError_t launch_bc(const EncLayerParams& p, const EncChain& nx, hipStream_t st) {
+  const int tiles = (p.Lk + BM - 1) / BM;
+  constexpr size_t lds = lds_bc_chain_bytes<T, DM, BM, NEXT>();
+  static_assert(lds <= 160 * 1024, "enc_bc tile does not fit LDS");
+  hipLaunchKernelGGL((enc_bc_kernel<T, DM, BM, NEXT>), dim3(p.B * tiles), dim3(512), lds, st, p, nx);
+  return hipGetLastError();
+}
+
+// variants with a compiled chain: mode 1 for the attention layers (DM = 384, tiles up to 32 rows: LDS), mode 2 for enc5
+template <typename T, int DM, int BM>
+constexpr bool has_chain(int mode) {
+  return (mode == 1 && DM == 384 && BM <= 32) || (mode == 2 && DM == 256 && BM >= 32);
 }
 
 template <typename T, int DM, int BM>
-hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st) {
+hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
   const int tiles = (p.Lk + BM - 1) / BM;
   const size_t red = 2 * 8 * BM * sizeof(float);
   if (which == 0) {
-    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red + (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16);
+    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red + enc_a_text_kv_bytes<T, DM, BM>();
     hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
-  } else {
-    const size_t lds = lds_bc_bytes<T, DM, BM>();
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((enc_bc_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
+    return hipGetLastError();
   }
-  return hipGetLastError();
+  if constexpr (lds_bc_bytes<T, DM, BM>() > 160 * 1024) {
+    return hipErrorInvalidValue;
+  } else {
+    if (chain && chain->mode) {
+      if (chain->a.x) return hipErrorInvalidValue;   // the chained layer reads its x tile from LDS
+      if constexpr (has_chain<T, DM, BM>(1)) { if (chain->mode == 1 && chain->a.d == DM) return launch_bc<T, DM, BM, 1>(p, *chain, st); }
+      if constexpr (has_chain<T, DM, BM>(2)) { if (chain->mode == 2 && chain->a.d == 384 && !(p.Lk & 1)) return launch_bc<T, DM, BM, 2>(p, *chain, st); }
+      return hipErrorInvalidValue;
+    }
+    return launch_bc<T, DM, BM, 0>(p, EncChain{}, st);
+  }
+}
+
+template <typename T, int DM, int BM, int NEXT>
+hipError_t attr_bc() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bc_kernel<T, DM, BM, NEXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <typename T, int DM, int BM>
@@ -480,20 +602,24 @@ hipError_t attr() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM, BM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bc_kernel<T, DM, BM>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if constexpr (lds_bc_bytes<T, DM, BM>() <= 160 * 1024) {
+    if ((e = attr_bc<T, DM, BM, 0>()) != hipSuccess) return e;
+    if constexpr (has_chain<T, DM, BM>(1)) { if ((e = attr_bc<T, DM, BM, 1>()) != hipSuccess) return e; }
+    if constexpr (has_chain<T, DM, BM>(2)) { if ((e = attr_bc<T, DM, BM, 2>()) != hipSuccess) return e; }
+  }
+  return hipSuccess;
 }
 
-// 64-row tiles when that still gives every CU a workgroup, else 32-row tiles (twice the workgroups)
+// row tile: 64 rows when that still gives every CU a workgroup, else 32, else 16 (twice / four times the workgroups)
 template <typename T, int DM>
-hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st) {
+int pick_bm(int B, int Lk, int bm_min = 0) {
   const char* e = getenv("DHW_ENC_BM");
   const int force = e ? atoi(e) : 0;
   const char* t = getenv("DHW_ENC_WGS");
   const long target = t ? atol(t) : 256;   // smallest tile count that still gives every CU a workgroup
   int bm = 64;
-  if ((long)p.B * ((p.Lk + 63) / 64) < target) bm = 32;
-  if (DM % 128 == 0 && (long)p.B * ((p.Lk + 31) / 32) < target) bm = 16;   // (the 4x2 wave layout of DM=192 needs >= 32 rows)
+  if ((long)B * ((Lk + 63) / 64) < target) bm = 32;
+  if (DM % 128 == 0 && (long)B * ((Lk + 31) / 32) < target) bm = 16;   // (the 4x2 wave layout of DM=192 needs >= 32 rows)
   if (force) bm = force;
   // LDS budget (160 KiB) of enc_bc: the three stage tiles, or the a2 tile + one 64-key K/V block; shrink the row tile until it fits
   auto lds_bc = [](int m) {
@@ -502,8 +628,15 @@ hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st) {
   };
   while (bm > 16 && lds_bc(bm) > 160 * 1024) bm /= 2;
   if (DM % 128 != 0 && bm < 32) bm = 32;
-  if (bm == 16) return launch_pair<T, DM, (DM % 128 == 0 ? 16 : 32)>(p, which, st);
-  return bm == 32 ? launch_pair<T, DM, 32>(p, which, st) : launch_pair<T, DM, 64>(p, which, st);
+  if (bm < bm_min) bm = bm_min;
+  return bm == 16 || bm == 32 ? bm : 64;
+}
+
+template <typename T, int DM>
+hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
+  const int bm = pick_bm<T, DM>(p.B, p.Lk, p.bm_min);
+  if (bm == 16) return launch_pair<T, DM, (DM % 128 == 0 ? 16 : 32)>(p, which, st, chain);
+  return bm == 32 ? launch_pair<T, DM, 32>(p, which, st, chain) : launch_pair<T, DM, 64>(p, which, st, chain);
 }
 
 }  // namespace
@@ -525,12 +658,19 @@ bool enclayer_supported(int prec, int d, int heads) {
 }
 
 // which: 0 = enc_a (cross attention half + q/k/v projection), 1 = enc_bc (self attention + FFN half)
-hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st) {
-  if (!enclayer_supported(prec, p.d, p.heads) || (p.pool && (p.Lk & 1))) return hipErrorInvalidValue;
+bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_next) {
+  if (prec != PREC_BF16) return false;
+  if (mode == 1) return d == 384 && d_next == 384 && pick_bm<bf16_t, 384>(B, Lk) <= 32;
+  if (mode == 2) return d == 256 && d_next == 384 && (Lk & 1) == 0;   // (with bm_min = 32)
+  return false;
+}
+
+hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
+  if (!enclayer_supported(prec, p.d, p.heads) || (p.pool && (p.Lk & 1)) || (chain && chain->mode && which != 1)) return hipErrorInvalidValue;
   switch (p.d) {
-    case 192: return launch_bm<bf16_t, 192>(p, which, st);
-    case 256: return launch_bm<bf16_t, 256>(p, which, st);
-    case 384: return launch_bm<bf16_t, 384>(p, which, st);
+    case 192: return launch_bm<bf16_t, 192>(p, which, st, chain);
+    case 256: return launch_bm<bf16_t, 256>(p, which, st, chain);
+    case 384: return launch_bm<bf16_t, 384>(p, which, st, chain);
   }
   return hipErrorInvalidValue;
 }
