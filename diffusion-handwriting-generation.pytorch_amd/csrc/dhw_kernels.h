@@ -41,12 +41,15 @@ struct GemmParams {
   void* pool;            // optional second output: AvgPool1d(2) over rows, [B*L/2, N]
   void* vt;              // [B][N-n_store][vt_lpad] element type (keys contiguous)
   int vt_lpad;
+  unsigned long long* stamps;   // diagnostics only: phase times (s_memrealtime) of the middle workgroup, or null
 };
 
 // returns hipError; chooses the tile from (prec, L, N, ln)
 hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st);
 // tile actually chosen (for tests / work accounting)
 void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN);
+hipError_t gemm_init();
+
 
 // heads (+ optional fused scheduler step).  x: fp32 [rows, C] (dec1 output).
 struct HeadsParams {

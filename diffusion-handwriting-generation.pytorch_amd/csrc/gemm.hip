@@ -21,13 +21,20 @@
 // A workgroup = 4 waves computes BM rows (of one sample) x BN channels; waves
 // are arranged WM x WN, each owning (BM/WM) x (BN/WN).
 #include <algorithm>
+#include <cstdlib>
 #include "gemm_core.h"
 #include "dhw_kernels.h"
 
 namespace {
 
+#define GSTAMP(slot)                                                                                               \
+  do {                                                                                                             \
+    if (p.stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) {
+  constexpr int NTHR = WM * WN * 64;
   constexpr int MT = BM / WM / 16;   // activation (column) tiles per wave
   constexpr int NT = BN / WN / 16;   // channel (row) tiles per wave
   constexpr int ES = sizeof(T);
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
   float* red = reinterpret_cast<float*>(smem + off);   // [2][WN][BM]
 
+  GSTAMP(0);
   // ---- stage activations (zero outside the sample: 'same' padding and row tail)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -72,12 +80,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int total = rows * cpr;
     const char* src = reinterpret_cast<const char*>(sg.A);
     constexpr int U = 4;   // independent 16-byte loads in flight per thread
-    for (int base = tid; base < total; base += 256 * U) {
+    for (int base = tid; base < total; base += NTHR * U) {
       uint4 v[U];
       int dst[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int id = base + u * 256;
+        const int id = base + u * NTHR;
         const int r = id / cpr, cc = id - r * cpr;
         const int lrow = m0 - halo + r;
         v[u] = make_uint4(0, 0, 0, 0);
@@ -97,6 +105,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
   __syncthreads();
+  GSTAMP(1);
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
 
+  GSTAMP(2);
   // ---------------------------------------------------------------- epilogue
   const float* bias_last = p.nseg == 2 ? p.bias1 : p.bias0;
 #pragma unroll
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   // ---- final epilogue -> output tile in LDS -> whole coalesced rows to global (per-lane 8-byte stores straight from
   // the accumulators touch 16 rows per instruction and are store-issue bound).  A workgroup's BN columns are either all
   // regular output columns or all transposed-V columns (the launcher picks BN | n_store).
+  GSTAMP(3);
   const bool vblock = nb0 >= p.n_store;
   constexpr int SOT = BN * ES + 16, SOF = BN * 4 + 16, SVT = BM * ES + 16;
   __syncthreads();   // every wave is done with the operand tiles: reuse LDS
@@ -272,23 +283,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   }
   __syncthreads();
+  GSTAMP(4);
   const int rows_valid = min(BM, p.L - m0);
   if (vblock) {
     constexpr int EPV = 16 / ES, PPR = BM / EPV;
     const int NV = p.N - p.n_store;
     T* vt = reinterpret_cast<T*>(p.vt) + ((size_t)b * NV + (nb0 - p.n_store)) * p.vt_lpad + m0;
-    for (int id = tid; id < BN * PPR; id += 256) {
+    for (int id = tid; id < BN * PPR; id += NTHR) {
       const int ch = id / PPR, part = id - ch * PPR;
       if (m0 + (part + 1) * EPV <= p.vt_lpad)
         *reinterpret_cast<uint4*>(vt + (size_t)ch * p.vt_lpad + part * EPV) = *reinterpret_cast<const uint4*>(smem + ch * SVT + part * 16);
     }
   } else if (p.out_f32) {
-    tile_copy_out<float>(smem, SOF, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, 256);
+    tile_copy_out<float>(smem, SOF, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, NTHR);
   } else {
-    tile_copy_out<T>(smem, SOT, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, 256);
+    tile_copy_out<T>(smem, SOT, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * p.n_store + nb0, p.n_store, rows_valid, BN, tid, NTHR);
     if (p.pool)
-      tile_copy_out_pool<T>(smem, SOT, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * p.N + nb0, p.N, rows_valid, BN, tid, 256);
+      tile_copy_out_pool<T>(smem, SOT, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * p.N + nb0, p.N, rows_valid, BN, tid, NTHR);
   }
+  GSTAMP(5);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -299,15 +312,28 @@ hipError_t launch_one(const GemmParams& p, hipStream_t st) {
   for (int s = 0; s < p.nseg; ++s)
     lds += (size_t)(BM + (p.seg[s].taps == 3 ? 2 : 0)) * (p.seg[s].C * sizeof(T) + 16);
   lds += 2 * WN * BM * sizeof(float);
-  const size_t out_tile = std::max((size_t)BM * (BN * 4 + 16), (size_t)BN * (BM * sizeof(T) + 16));
+  const size_t out_tile = std::max((size_t)BM * (BN * (p.out_f32 ? 4 : sizeof(T)) + 16), p.n_store < p.N ? (size_t)BN * (BM * sizeof(T) + 16) : 0);
   lds = std::max(lds, out_tile);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, st, p);
   return hipGetLastError();
+}
+
+// The widest blocks run as 8 narrower waves (NT = 3 / 2 channel tiles each instead of 6 / 4): a workgroup's life is a
+// latency chain (stage A -> weight stream -> epilogue), and the deep grids of the all-steps text plane want waves in
+// flight more than registers per wave (ts.dense 138 -> 121 us).  The choice must not depend on the batch: a prompt's
+// samples are bit-identical whatever batch it is sampled in (LayerNorm partial sums are grouped per wave).
+static bool wide_w8() {
+  static const bool on = !(getenv("DHW_GEMM_W8") && atoi(getenv("DHW_GEMM_W8")) == 0);
+  return on;
 }
 
 template <typename T, int BM>
 hipError_t launch_bn(int BN, const GemmParams& p, hipStream_t st) {
+  if (sizeof(T) == 2 && wide_w8()) {
+    if (BN == 384) return launch_one<T, BM, 384, 1, 8>(p, st);
+    if (BN == 256) return launch_one<T, BM, 256, 1, 8>(p, st);
+  }
   switch (BN) {
     case 64: return launch_one<T, BM, 64, 1, 4>(p, st);
     case 96: return launch_one<T, BM, 96, 2, 2>(p, st);
@@ -332,6 +358,8 @@ hipError_t set_attr_bm() {
   if ((e = set_attr<T, BM, 128, 1, 4>()) != hipSuccess) return e;
   if ((e = set_attr<T, BM, 192, 1, 4>()) != hipSuccess) return e;
   if ((e = set_attr<T, BM, 256, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 256, 1, 8>()) != hipSuccess) return e;
+  if ((e = set_attr<T, BM, 384, 1, 8>()) != hipSuccess) return e;
   return set_attr<T, BM, 384, 1, 4>();
 }
 
@@ -366,6 +394,10 @@ void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
     if (!bn)
       for (int k = 5; k >= 0; --k)
         if (ok(cands[k])) { bn = cands[k]; break; }
+    if (const char* e = getenv("DHW_GEMM_BN")) {   // experiments only
+      const int f = atoi(e);
+      if (f > 0 && ok(f)) bn = f;
+    }
   }
   *BM = bm;
   *BN = bn;
