@@ -177,20 +177,24 @@ def kernel_profile(model, one_step):
     return roof, table
 
 
+PMC_FILE = "r01_v6_hbm_traffic_pmc.json"
+
+
 def pmc_traffic(label):
     """HBM-side bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC collection serialises kernels, so it is not repeated inside
     the timed run; None when no measurement for this kernel class has been committed."""
-    name = {"enc.fused_bc": "enc_bc_kernel", "enc.fused_a": "enc_a_kernel", "convblock.fused": "convblock_kernel"}.get(label)
-    path = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic_pmc.json")
+    name = {"enc.fused_bc": "enc_bc_kernel", "enc.fused_bc+a": "enc_bc_kernel", "enc.fused_a": "enc_a_kernel",
+            "convblock.fused": "convblock_kernel"}.get(label)
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if not name or not os.path.exists(path):
         return None
     try:
         with open(path) as f:
             k = json.load(f)["kernels"].get(name)
         return {"bytes_per_launch": k["hbm_bytes_per_launch"], "fetch": k["fetch_bytes_per_launch"],
-                "write": k["write_bytes_per_launch"], "source": "profiles/r01_v4_hbm_traffic_pmc.json"} if k else None
+                "write": k["write_bytes_per_launch"], "source": "profiles/" + PMC_FILE} if k else None
     except (OSError, ValueError, KeyError):
         return None
 
