@@ -84,11 +84,16 @@ constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * (DM * sizeof(T) + 1
 template <typename T, int DM, int BM, int VPIECE = 16>
 DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0, int rows_valid) {
   constexpr int ES = sizeof(T);
-  constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
+  // GEMM stages: every wave covers all BM rows and 1/WN of the channels, so no two waves stream the same weight
+  // fragments (row groups would re-fetch them: the L2 -> CU weight stream is what bounds these kernels).  DM = 192 has
+  // 12 channel tiles: 6 waves take 2 each, the other 2 waves only join the barriers (and the attention stage).
+  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
+  static_assert(NT * WN * 16 == DM, "channel tiles must divide over the waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool act = WN == 8 || wave < WN;
+  const int wm = 0, wn = act ? wave : 0;
   const int S = tile_stride<T>(DM);
   char* XR = m.XR;
   char* QR = m.QR;
@@ -104,8 +109,10 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   WRing<T, NT> ring;
   EpiParams<NT> ep;
   STAMP(0);
-  ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
-  ep.load(p.b_q1, nullptr, nullptr, n0);
+  if (act) {
+    ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
+    ep.load(p.b_q1, nullptr, nullptr, n0);
+  }
   if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
   // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
   constexpr int KBC = 32, SKC = DM * ES + 16, SVC = KBC * ES + 16;
@@ -117,7 +124,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   lds_barrier();
   STAMP(1);
 
-  {  // ---- q1 = Wq x + b + PE·Wq[row]
+  if (act) {  // ---- q1 = Wq x + b + PE·Wq[row]
     f32x4 acc[NT][MT];
     acc_zero(acc);
     f32x4 pb[NT][MT];
@@ -185,32 +192,38 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
       }
     }
   }
-  ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
-  ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
+  if (act) {
+    ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
+    ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
+  }
   lds_barrier();
   STAMP(3);
 
   {  // ---- x2 = FiLM1(LN(Wd a1 + b)) + x
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    ring.template run<MT>(acc, qop, S, KC);
-    STAMP(10);
-    ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + wlane, KC);   // q2 chunk: flies during the LayerNorm epilogue
+    if (act) {
+      ring.template run<MT>(acc, qop, S, KC);
+      STAMP(10);
+      ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + wlane, KC);   // q2 chunk: flies during the LayerNorm epilogue
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
-    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);
+        for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
+    }
+    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
     STAMP(11);
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r = row0 + j * 16 + l15;
-        T* xp = reinterpret_cast<T*>(XR + r * S) + n0 + 16 * i;
-        const f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(xp);
-        store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
-      }
+        for (int j = 0; j < MT; ++j) {
+          const int r = row0 + j * 16 + l15;
+          T* xp = reinterpret_cast<T*>(XR + r * S) + n0 + 16 * i;
+          const f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(xp);
+          store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
+        }
+    }
   }
   lds_barrier();
   STAMP(4);
@@ -224,22 +237,24 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     asm volatile("" : "+v"(opaque));
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    ep.load(p.b_qkv2 + chunk * DM, nullptr, nullptr, n0 + opaque);
     f32x4 pb[NT][MT];
-    if (chunk < 2) {
+    if (act) {
+      ep.load(p.b_qkv2 + chunk * DM, nullptr, nullptr, n0 + opaque);
+      if (chunk < 2) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
-          pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
+          for (int j = 0; j < MT; ++j)
+            pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
+      }
+      ring.template run<MT>(acc, xop + opaque, S, KC);
+      STAMP(12 + chunk);
+      if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
     }
-    ring.template run<MT>(acc, xop + opaque, S, KC);
-    STAMP(12 + chunk);
-    if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
     if (chunk < 2 && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
       const int r = row0 + l15;
-      if (r < rows_valid) {
+      if (act && r < rows_valid) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
           store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
@@ -250,27 +265,31 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V) is free: every wave is past its readers
     if (chunk < 2) {
       // q2 / k2 chunk -> LDS tile [row][DM] -> coalesced rows of qk2 [.., 2*DM]
+      if (act) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
-          store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i + opaque, acc[i][j] + ep.bias[i] + pb[i][j]);
+          for (int j = 0; j < MT; ++j)
+            store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i + opaque, acc[i][j] + ep.bias[i] + pb[i][j]);
+      }
       lds_barrier();
       tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * 2 * DM + chunk * DM, 2 * DM, rows_valid, DM, tid, 512);
     } else {
       // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2
       constexpr int SV = BM * ES + 16;
       char* VS = m.VS;
+      if (act) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int rl = row0 + j * 16 + l15;
-          const f32x4 v = acc[i][j] + ep.bias[i];
+          for (int j = 0; j < MT; ++j) {
+            const int rl = row0 + j * 16 + l15;
+            const f32x4 v = acc[i][j] + ep.bias[i];
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<T*>(VS + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(rl < rows_valid ? v[k] : 0.f);
-        }
+            for (int k = 0; k < 4; ++k)
+              *reinterpret_cast<T*>(VS + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(rl < rows_valid ? v[k] : 0.f);
+          }
+      }
       lds_barrier();
       // keys this tile owns: its valid rows; the sample's last tile also zero-fills the padding up to lpadX
       constexpr int KPP = VPIECE / ES, PPR = BM / KPP;   // keys per piece, pieces per channel row
@@ -330,13 +349,14 @@ constexpr size_t lds_bc_chain_bytes() {
 template <typename T, int DM, int BM, int NEXT = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_bc_kernel(const EncLayerParams p, const EncChain nx) {
   constexpr int ES = sizeof(T);
-  constexpr int WN = (DM % 128 == 0) ? 8 : 4, WM = 8 / WN;   // waves: WM row groups x WN channel groups
+  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   constexpr int RING = DM == 384 ? 15 : 24;   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
+  const int wm = 0, wn = act ? wave : 0;
   const int tiles = (p.Lk + BM - 1) / BM;
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);   // the row tiles of one sample run on one XCD (shared K/V in its L2)
   const int b = bid / tiles, m0 = (bid % tiles) * BM;
@@ -411,42 +431,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
-  ring.fill(reinterpret_cast<const T*>(p.w_d2) + wlane, KC);   // in flight across the barrier
-  ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
+  if (act) {
+    ring.fill(reinterpret_cast<const T*>(p.w_d2) + wlane, KC);   // in flight across the barrier
+    ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
+  }
   lds_barrier();
   STAMP(17);
 
   {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    f32x4 res[NT][MT];
+    if (act) {
+      f32x4 res[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r = m0 + row0 + j * 16 + l15;
-        res[i][j] = r < p.Lk ? load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i))
-                             : (f32x4){0, 0, 0, 0};
-      }
-    ring.template run<MT>(acc, op1, S, KC);
-    ring.fill(reinterpret_cast<const T*>(p.w_f1) + wlane, KC);   // FFN half 0: flies during the LayerNorm epilogue
+        for (int j = 0; j < MT; ++j) {
+          const int r = m0 + row0 + j * 16 + l15;
+          res[i][j] = r < p.Lk ? load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i))
+                               : (f32x4){0, 0, 0, 0};
+        }
+      ring.template run<MT>(acc, op1, S, KC);
+      ring.fill(reinterpret_cast<const T*>(p.w_f1) + wlane, KC);   // FFN half 0: flies during the LayerNorm epilogue
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
+        for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
+    }
     STAMP(18);
-    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM);   // its barriers also fence the a2 reads above
+    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int r = row0 + j * 16 + l15;
-        f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
-        store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
+        for (int j = 0; j < MT; ++j) {
+          const int r = row0 + j * 16 + l15;
+          f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
+          store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
-        store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
-      }
+          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
+          store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
+        }
+    }
   }
   lds_barrier();
   STAMP(19);
@@ -456,7 +482,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   acc_zero(acc2);
 #pragma unroll 1
   for (int hh = 0; hh < 2; ++hh) {
-    {
+    if (act) {
       f32x4 acc[NT][MT];
       acc_zero(acc);
       ep.load(p.b_f1 + hh * DM, nullptr, nullptr, n0);
@@ -475,24 +501,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     lds_barrier();
     STAMP(20 + 2 * hh);
-    ring.template run<MT>(acc2, op3, S, KC);
-    if (hh == 0) ring.fill(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane, KC);   // FFN half 1
+    if (act) {
+      ring.template run<MT>(acc2, op3, S, KC);
+      if (hh == 0) ring.fill(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane, KC);   // FFN half 1
+    }
     lds_barrier();   // R3 is rewritten by the next half
     STAMP(21 + 2 * hh);
   }
-  ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
+  if (act) {
+    ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
-      acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
-  layernorm_rows<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM);
+      for (int j = 0; j < MT; ++j)
+        acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
+  }
+  layernorm_rows<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
   // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
+  if (act) {
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
-      store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc2[i][j] * ep.gam[i] + ep.bet[i]);
+      for (int j = 0; j < MT; ++j)
+        store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc2[i][j] * ep.gam[i] + ep.bet[i]);
+  }
   lds_barrier();
   const int rows_valid = min(BM, p.Lk - m0);
   tile_copy_out<T>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
@@ -613,7 +645,8 @@ hipError_t attr() {
 // row tile: 64 rows when that still gives every CU a workgroup, else 32, else 16 (twice / four times the workgroups)
 template <typename T, int DM>
 int pick_bm(int B, int Lk, int bm_min = 0) {
-  const char* e = getenv("DHW_ENC_BM");
+  const char* e = getenv(DM == 384 ? "DHW_ENC_BM384" : DM == 256 ? "DHW_ENC_BM256" : "DHW_ENC_BM192");   // experiments only
+  if (!e) e = getenv("DHW_ENC_BM");
   const int force = e ? atoi(e) : 0;
   const char* t = getenv("DHW_ENC_WGS");
   const long target = t ? atol(t) : 256;   // smallest tile count that still gives every CU a workgroup

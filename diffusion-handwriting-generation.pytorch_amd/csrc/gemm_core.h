@@ -132,8 +132,9 @@ DHW_DEV void acc_zero(f32x4 (&acc)[NT][MT]) {
 // LayerNorm (eps 1e-6, no affine; reference model.py:25) over the N channels of each row of a tile whose
 // channels are split over WN waves (each holding NT tiles of 16) — two-pass, fp32.
 // red: LDS scratch of 2*WN*ROWS floats.  Row of (j, lane): row0 + j*16 + (lane&15).  Contains barriers.
+// act = false: a wave that owns no channels of this stage (it only takes part in the barriers).
 template <int MT, int NT, int WN, int ROWS>
-DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N) {
+DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true) {
   const int l15 = lane & 15, g = lane >> 4;
   float mean[MT], rstd[MT];
 #pragma unroll
@@ -143,7 +144,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
     for (int i = 0; i < NT; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (g == 0) red[wn * ROWS + row0 + j * 16 + l15] = s;
+    if (g == 0 && act) red[wn * ROWS + row0 + j * 16 + l15] = s;
   }
   lds_barrier();
   const float invn = 1.0f / (float)N;
@@ -163,7 +164,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
       for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (g == 0) red[(WN + wn) * ROWS + row0 + j * 16 + l15] = s;
+    if (g == 0 && act) red[(WN + wn) * ROWS + row0 + j * 16 + l15] = s;
   }
   lds_barrier();
 #pragma unroll
