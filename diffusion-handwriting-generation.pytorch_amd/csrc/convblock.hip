@@ -14,8 +14,7 @@
 // bf16: 8 waves (2 per SIMD), BM = 64.  fp32 (parity mode): 4 waves, BM = 32 (LDS budget).
 #include <algorithm>
 #include <cstdlib>
-#include "gemm_core.h"
-#include "dhw_kernels.h"
+#include "enc_a_core.h"
 #include "heads_core.h"
 
 namespace {
@@ -42,9 +41,10 @@ struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles,
 // VALU-heavy epilogue / staging overlaps the other's MFMA phases.
 // UPC = 0, or the block's input width Cin when the input itself is produced here (decoder blocks):
 // x = Upsample(low) + skip_conv(h) (model.py:169-175), one more 3-tap GEMM stage in front of the block.
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
+// CH = 1: the workgroup continues with enc_a of the EncoderLayer that follows the block (nx.a) on its output tile.
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
-void convblock_kernel(const ConvBlockParams p) {
+void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr int BMO = BM - 2;            // output rows per workgroup
   constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
@@ -329,6 +329,18 @@ void convblock_kernel(const ConvBlockParams p) {
     tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.pool)   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
       tile_copy_out_pool<T>(smem, SH2, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * CO, CO, rows_valid, CO, tid, NTHR);
+    if constexpr (CH == 1) {
+      // the output tile (rows [m0, m0 + rows_valid), row stride SH2 = tile_stride(CO)) is the next layer's x tile
+      static_assert(NW == 8 && sizeof(T) == 2, "enc_a_body runs on 8 waves");
+      EncALds m;
+      m.XR = smem;
+      m.QR = smem + BM * SH2;
+      m.red = reinterpret_cast<float*>(m.QR + BM * SH2);
+      m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
+      m.VT = m.KT + 32 * (CO * ES + 16);
+      m.VS = smem;
+      enc_a_body<T, CO, BM, 4>(nx.a, m, b, m0, rows_valid);   // (tile starts are multiples of BM - 2: even, not 8-aligned)
+    }
   }
   STAMP(9);
 }
@@ -342,18 +354,19 @@ size_t lds_bytes(int Cin, int up_cin = 0) {
   return std::max(ops, std::max(outf, up));
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
-hipError_t launch_t(const ConvBlockParams& p, hipStream_t st) {
-  const size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
-  if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32))) return hipErrorInvalidValue;
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
+hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
+  size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
+  if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>());
+  if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32)) || (CH != 0) != (nx != nullptr)) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p);
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -374,6 +387,9 @@ hipError_t convblock_init() {
   if ((e = attr<bf16_t, 64, 256, 8, 1, 384>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 48, 256, 8, 1, 384>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 48, 256, 8>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 192, 8, 1, 0, 1>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 48, 256, 8, 1, 0, 1>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 256, 8, 1, 0, 1>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
   if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
   return attr<float, 32, 256, 4>();
@@ -423,4 +439,19 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
     }
   }
   return hipErrorInvalidValue;
+}
+
+// The encoder-side blocks in front of an EncoderLayer (enc2 -> enc3, enc4 -> enc5): bf16, no fused input stage, no fp32
+// output, the block's width is the layer's width.
+bool convblock_chain_supported(int prec, const ConvBlockParams& p, const EncChain& chain) {
+  if (prec != PREC_BF16 || chain.mode != 1 || chain.a.x || p.up_h || p.strokes || p.out_f32 || p.fuse_heads) return false;
+  if (chain.a.d != p.Cout || chain.a.Lk != p.L || chain.a.B != p.B || (p.L & 1)) return false;
+  if (getenv("DHW_CONV_BM") || getenv("DHW_CONV_OCC")) return false;
+  return (p.Cout == 192 || p.Cout == 256) && enclayer_supported(prec, chain.a.d, chain.a.heads);
+}
+
+hipError_t launch_convblock_chain(int prec, const ConvBlockParams& p, const EncChain& chain, hipStream_t st) {
+  if (!convblock_chain_supported(prec, p, chain) || p.Cin % 32 || (!p.out)) return hipErrorInvalidValue;
+  if (p.Cout == 192) return launch_t<bf16_t, 64, 192, 8, 1, 0, 1>(p, st, &chain);
+  return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 0, 1>(p, st, &chain) : launch_t<bf16_t, 64, 256, 8, 1, 0, 1>(p, st, &chain);
 }

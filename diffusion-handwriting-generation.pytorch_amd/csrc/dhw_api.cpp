@@ -597,8 +597,11 @@ void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, 
 struct UpIn { const void* hskip; const void* w; const float* b; int cin; const void* low; };
 
 // cnn.py:64-87 as one fused launch (or three fused GEMM launches)
+// chain: the EncoderLayer half the block's workgroups continue with (EncChain mode 1), or null; *chained reports
+// whether the launch took it
 void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
-                void* pool, const float* strokes = nullptr, const UpIn* up = nullptr) {
+                void* pool, const float* strokes = nullptr, const UpIn* up = nullptr, const EncChain* chain = nullptr,
+                bool* chained = nullptr) {
   dhw_handle* h = c.h;
   if (h->fuse) {
     ConvBlockParams q{};
@@ -620,10 +623,14 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     if (!c.err) {
       const double rows = (double)c.B * L;
       const double upf = up ? 3.0 * up->cin * w.cin : 0.0;   // skip_conv MACs per row
-      Launch l(h, c.st, "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf),
+      const bool ch = chain && chain->mode && convblock_chain_supported(h->prec, q, *chain);
+      if (chained) *chained = ch;
+      const double dd = w.cout;
+      const double chf = ch ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd : 0.0, chb = ch ? rows * dd * 4 * h->es + 5.0 * dd * dd * h->es : 0.0;
+      Launch l(h, c.st, ch ? "convblock.fused+a" : "convblock.fused", 2.0 * rows * (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf) + chf,
                rows * ((up ? up->cin + 0.5 * w.cin : w.cin) * h->es + w.cout * (out_f32 ? 4.0 : (double)h->es) * (pool ? 1.5 : 1.0)) +
-                   (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf) * h->es);
-      hipError_t e = launch_convblock(h->prec, q, c.st);
+                   (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf) * h->es + chb);
+      hipError_t e = ch ? launch_convblock_chain(h->prec, q, *chain, c.st) : launch_convblock(h->prec, q, c.st);
       if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "convblock %s: %s", n.c_str(), hipGetErrorString(e));
     }
     tap(c, n, n, L, w.cout, out_f32);
@@ -942,13 +949,26 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
     tap(c, "input_dense", "x0", L, d.c1);
   }
   conv_block(c, "enc1", h->enc1, BUF(c, "x0"), L, BUF(c, "enc1"), false, BUF(c, "enc1.pool"), fin ? strokes : nullptr);
-  conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr);
-  enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"));
-  conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr);
-  // Everything between two self-attentions is row-local, so enc5's second half continues into AvgPool + att_dense + the
-  // first attention layer's first half, and every attention layer's second half into the next layer's first half.
+  // Everything between two self-attentions is row-local: enc2 / enc4 continue into the first half of enc3 / enc5,
+  // enc5's second half into AvgPool + att_dense + the first attention layer's first half, and every attention layer's
+  // second half into the next layer's first half.
   const bool chain_ok = h->fuse && h->chain && h->prec == PREC_BF16;
   const int nl = d.num_layers;
+  bool a3 = false, a5 = false;
+  // enc2 / enc4 can continue into enc3.a / enc5.a the same way (bit 0 / bit 1), but the ConvBlock's row tiling (62 / 46 rows)
+  // is a worse fit for the layer than its own: measured 23.22 ms (off) / 23.21 (enc3) / 23.40 (enc5, both) -> off by default
+  static const int conv_chain = getenv("DHW_CHAIN_CONV") ? atoi(getenv("DHW_CHAIN_CONV")) : 0;
+  {
+    EncChain ch{};
+    if (chain_ok && (conv_chain & 1)) { ch.mode = 1; ch.a = enc_params(c, "enc3", h->el[0], nullptr, L / 2, h->lpadX[0], text, nullptr); }
+    conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a3);
+  }
+  enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"), a3);
+  {
+    EncChain ch{};
+    if (chain_ok && (conv_chain & 2)) { ch.mode = 1; ch.a = enc_params(c, "enc5", h->el[1], nullptr, L / 4, h->lpadX[1], text, nullptr); }
+    conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a5);
+  }
   auto att_name = [](int i) { return "att_layers." + std::to_string(i); };
   EncChain ch5{};
   if (chain_ok && nl > 0 && enclayer_supported(h->prec, dt, h->el[2].heads) && enclayer_chain_supported(h->prec, d.c3, c.B, L / 4, 2, dt)) {
@@ -956,7 +976,7 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
     ch5.a = enc_params(c, att_name(0), h->el[2], nullptr, L / 8, h->lpadX[2], text, nullptr);
     ch5.w_dense = h->w_attd; ch5.b_dense = h->b_attd; ch5.dense_out = BUF(c, "att_dense");
   }
-  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"), false, ch5.mode ? &ch5 : nullptr,
+  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"), a5, ch5.mode ? &ch5 : nullptr,
             ch5.mode ? 32 : 0);
   if (!ch5.mode) {
     GemmParams p = gp_base(c, L / 8, dt);

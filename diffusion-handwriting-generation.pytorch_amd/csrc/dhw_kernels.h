@@ -120,6 +120,9 @@ struct EncChain {
   const void* w_dense; const float* b_dense;   // mode 2: packed weight [a.d x d], bias [a.d]
   void* dense_out;           // mode 2: Linear output [B*Lk/2, a.d] (kept for debug taps)
 };
+// A ConvBlock whose output feeds an EncoderLayer continues into that layer's enc_a on its own output tile (mode 1).
+bool convblock_chain_supported(int prec, const ConvBlockParams& p, const EncChain& chain);
+hipError_t launch_convblock_chain(int prec, const ConvBlockParams& p, const EncChain& chain, hipStream_t st);
 bool enclayer_supported(int prec, int d, int heads);
 // whether enc_bc of a (d, B, Lk) layer can continue with `mode`; mode 2 needs EncLayerParams.bm_min = 32 on that layer
 bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_next);

@@ -10,303 +10,14 @@
 //
 // GEMM stages: waves WM (row groups) x WN (channel groups), weights streamed from L2 in fragment order
 // (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
-#include "attn_core.h"
-#include "gemm_core.h"
 #include <algorithm>
 #include <cstdlib>
-#include "dhw_kernels.h"
+#include "enc_a_core.h"
 
 namespace {
 
 
-// diagnostic stage stamps (100 MHz s_memrealtime), only when the caller passes a buffer
-#define STAMP(slot)                                                                                   \
-  do {                                                                                                \
-    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-
-template <typename T, int BM>
-DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
-  constexpr int ES = sizeof(T);
-  const int cpr = C * ES / 16;
-  const int total = BM * cpr;
-  constexpr int U = 4;
-  for (int base = tid; base < total; base += nthreads * U) {
-    uint4 v[U];
-    int off[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int id = base + u * nthreads;
-      const int r = id / cpr, cc = id - r * cpr;
-      v[u] = make_uint4(0, 0, 0, 0);
-      off[u] = id < total ? r * S + cc * 16 : -1;
-      if (id < total && m0 + r < L)
-        v[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + ((size_t)(b * L + m0 + r) * C) * ES + (size_t)cc * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (off[u] >= 0) *reinterpret_cast<uint4*>(dst + off[u]) = v[u];
-  }
-}
-
-// epilogue parameters of one stage (this lane's 4 channels of each of its NT channel tiles), requested BEFORE the
-// stage's main loop so their L2 latency is hidden behind it
-template <int NT>
-struct EpiParams {
-  f32x4 bias[NT], gam[NT], bet[NT];
-  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {   // n0: first channel of this lane
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
-      gam[i] = g ? *reinterpret_cast<const f32x4*>(g + n0 + 16 * i) : (f32x4){1, 1, 1, 1};
-      bet[i] = be ? *reinterpret_cast<const f32x4*>(be + n0 + 16 * i) : (f32x4){0, 0, 0, 0};
-    }
-  }
-};
-
-// LDS regions of the enc_a stages.  XR and QR are [BM][DM] tiles (row stride tile_stride(DM)); VS is the staging area of the
-// transposed v2 tile (DM rows of BM keys), free to overlay XR / QR; KT / VT hold one 32-key block of text keys / values.
-struct EncALds {
-  char* XR;     // x, later x2
-  char* QR;     // q1, later a1
-  float* red;   // LayerNorm partial sums [2][8][BM]
-  char* KT;
-  char* VT;
-  char* VS;
-};
-template <typename T, int DM, int BM>
-constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16); }
-
-// enc_a for the BM-row tile [m0, m0+BM) of sample b, of which the first rows_valid rows are this workgroup's to write.
-// p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
-// ConvBlock or the previous layer's enc_bc continues into the next layer without a launch boundary.  VPIECE = bytes per
-// store of the transposed v2 tile (16, or 4 when m0 is only even).
-template <typename T, int DM, int BM, int VPIECE = 16>
-DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0, int rows_valid) {
-  constexpr int ES = sizeof(T);
-  // GEMM stages: every wave covers all BM rows and 1/WN of the channels, so no two waves stream the same weight
-  // fragments (row groups would re-fetch them: the L2 -> CU weight stream is what bounds these kernels).  DM = 192 has
-  // 12 channel tiles: 6 waves take 2 each, the other 2 waves only join the barriers (and the attention stage).
-  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;
-  constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  static_assert(NT * WN * 16 == DM, "channel tiles must divide over the waves");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const bool act = WN == 8 || wave < WN;
-  const int wm = 0, wn = act ? wave : 0;
-  const int S = tile_stride<T>(DM);
-  char* XR = m.XR;
-  char* QR = m.QR;
-  float* red = m.red;
-  const float* gam = p.film + (size_t)b * p.film_bs;
-  const float* bet = gam + p.film_tot;
-  const int row0 = wm * (BM / WM), ntile0 = wn * NT;
-  const int n0 = ntile0 * 16 + 4 * g;                          // this lane's first channel
-  const size_t wlane = ((size_t)ntile0 * KC * 64 + lane) * 8;  // this wave/lane's offset into a packed [DM x DM] block
-  const char* xop = XR + (row0 + l15) * S + g * 8 * ES;
-  const char* qop = QR + (row0 + l15) * S + g * 8 * ES;
-
-  WRing<T, NT> ring;
-  EpiParams<NT> ep;
-  STAMP(0);
-  if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
-    ep.load(p.b_q1, nullptr, nullptr, n0);
-  }
-  if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
-  // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
-  constexpr int KBC = 32, SKC = DM * ES + 16, SVC = KBC * ES + 16;
-  char* KT = m.KT;
-  char* VT = m.VT;
-  const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
-  const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
-  attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
-  lds_barrier();
-  STAMP(1);
-
-  if (act) {  // ---- q1 = Wq x + b + PE·Wq[row]
-    f32x4 acc[NT][MT];
-    acc_zero(acc);
-    f32x4 pb[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j)
-        pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + row0 + j * 16 + l15) * DM + n0 + 16 * i));
-    ring.template run<MT>(acc, xop, S, KC);
-    STAMP(8);
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j)
-        store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc[i][j] + ep.bias[i] + pb[i][j]);
-    STAMP(9);
-  }
-  lds_barrier();
-  STAMP(2);
-
-  {  // ---- cross attention over the Lt text keys (K/V staged in LDS, 32 keys per block); a1 overwrites q1 in place
-    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS;
-    constexpr int SK = SKC, SV = SVC;
-    const int rg = wave % RG, hs = wave / RG;
-    Frag<T> qf[UMAX][2];
-    float mr[UMAX], lr[UMAX];
-    f32x4 o[UMAX][4];
-#pragma unroll
-    for (int u = 0; u < UMAX; ++u) {
-      const int h = hs + u * HS;
-      const T* qrow = reinterpret_cast<const T*>(QR + (rg * 16 + l15) * S) + (h < H ? h : 0) * 64 + 8 * g;
-      qf[u][0] = frag_load(qrow);
-      qf[u][1] = frag_load(qrow + 32);
-      mr[u] = -INFINITY;
-      lr[u] = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
-    }
-    const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
-    for (int kb = 0; kb < p.Lt; kb += KBC) {
-      if (kb) {
-        attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
-        lds_barrier();
-      }
-#pragma unroll
-      for (int u = 0; u < UMAX; ++u) {
-        const int h = hs + u * HS;
-        if (h < H)
-          attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, trow,
-                                     p.Lt, mr[u], lr[u], o[u]);
-      }
-      lds_barrier();   // the staging tiles are rewritten by the next block
-    }
-#pragma unroll
-    for (int u = 0; u < UMAX; ++u) {
-      const int h = hs + u * HS;
-      float l = lr[u];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      const float inv = 1.0f / l;
-      if (h < H) {
-        T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
-      }
-    }
-  }
-  if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
-    ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
-  }
-  lds_barrier();
-  STAMP(3);
-
-  {  // ---- x2 = FiLM1(LN(Wd a1 + b)) + x
-    f32x4 acc[NT][MT];
-    acc_zero(acc);
-    if (act) {
-      ring.template run<MT>(acc, qop, S, KC);
-      STAMP(10);
-      ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + wlane, KC);   // q2 chunk: flies during the LayerNorm epilogue
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
-    }
-    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
-    STAMP(11);
-    if (act) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int r = row0 + j * 16 + l15;
-          T* xp = reinterpret_cast<T*>(XR + r * S) + n0 + 16 * i;
-          const f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(xp);
-          store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
-        }
-    }
-  }
-  lds_barrier();
-  STAMP(4);
-  tile_copy_out<T>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
-
-  // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
-  // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
-#pragma unroll 1
-  for (int chunk = 0; chunk < 3; ++chunk) {
-    int opaque = 0;
-    asm volatile("" : "+v"(opaque));
-    f32x4 acc[NT][MT];
-    acc_zero(acc);
-    f32x4 pb[NT][MT];
-    if (act) {
-      ep.load(p.b_qkv2 + chunk * DM, nullptr, nullptr, n0 + opaque);
-      if (chunk < 2) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j)
-            pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
-      }
-      ring.template run<MT>(acc, xop + opaque, S, KC);
-      STAMP(12 + chunk);
-      if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
-    }
-    if (chunk < 2 && MT == 1) {
-      // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
-      const int r = row0 + l15;
-      if (act && r < rows_valid) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
-      }
-      STAMP(5 + chunk);
-      continue;
-    }
-    lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V) is free: every wave is past its readers
-    if (chunk < 2) {
-      // q2 / k2 chunk -> LDS tile [row][DM] -> coalesced rows of qk2 [.., 2*DM]
-      if (act) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j)
-            store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i + opaque, acc[i][j] + ep.bias[i] + pb[i][j]);
-      }
-      lds_barrier();
-      tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * 2 * DM + chunk * DM, 2 * DM, rows_valid, DM, tid, 512);
-    } else {
-      // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2
-      constexpr int SV = BM * ES + 16;
-      char* VS = m.VS;
-      if (act) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j) {
-            const int rl = row0 + j * 16 + l15;
-            const f32x4 v = acc[i][j] + ep.bias[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              *reinterpret_cast<T*>(VS + (n0 + 16 * i + k) * SV + rl * ES) = from_f<T>(rl < rows_valid ? v[k] : 0.f);
-          }
-      }
-      lds_barrier();
-      // keys this tile owns: its valid rows; the sample's last tile also zero-fills the padding up to lpadX
-      constexpr int KPP = VPIECE / ES, PPR = BM / KPP;   // keys per piece, pieces per channel row
-      const int klimit = m0 + rows_valid >= p.Lk ? min(BM, p.lpadX - m0) : rows_valid;
-      for (int id = tid; id < DM * PPR; id += 512) {
-        const int ch = id / PPR, part = id - ch * PPR;
-        if ((part + 1) * KPP <= klimit) {
-          T* dst = reinterpret_cast<T*>(p.vt2) + ((size_t)b * DM + ch) * p.lpadX + m0 + part * KPP;
-          const char* src = VS + ch * SV + part * VPIECE;
-          if constexpr (VPIECE == 16) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-          else *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
-        }
-      }
-    }
-    STAMP(5 + chunk);
-  }
-}
+#define STAMP(slot) ENC_STAMP(slot)
 
 template <typename T, int DM, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {

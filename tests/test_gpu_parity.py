@@ -299,7 +299,7 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
     outs = {}
     for name, env in (("default", {}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
-                      ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("no_chain", {"DHW_CHAIN": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
+                      ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("no_chain", {"DHW_CHAIN": "0"}), ("conv_chain", {"DHW_CHAIN_CONV": "3"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
         outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
     assert torch.equal(outs["default"], outs["no_plane"])
@@ -307,6 +307,7 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     assert (outs["default"] - outs["no_fused_heads"]).abs().max().item() < tol
     assert (outs["default"] - outs["no_fused_up"]).abs().max().item() < tol   # (bf16 only: fp32 keeps the separate GEMM)
     assert (outs["default"] - outs["no_chain"]).abs().max().item() < tol      # (bf16 only)
+    assert (outs["default"] - outs["conv_chain"]).abs().max().item() < tol    # (bf16 only; off by default)
     assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
 
 
