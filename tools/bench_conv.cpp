@@ -1,4 +1,5 @@
 // bench_conv.cpp — isolated timing + per-stage stamps of the fused ConvBlock kernel on the six real block shapes.
+// Build: hipcc -c tools/bench_conv.cpp -o tools/bin/bench_conv.o; hipcc tools/bin/bench_conv.o <pkg>/build/convblock.o <pkg>/build/enclayer.o -o tools/bin/bench_conv
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
