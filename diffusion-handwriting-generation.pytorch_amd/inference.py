@@ -70,3 +70,49 @@ def infer(prompt: str, style_vector: torch.Tensor, model: DiffusionModel, diffus
     text = torch.tensor([ids], dtype=torch.int64)
     out = sample(model, text, style_vector, L=stroke_length(len(ids)), T=T, diffusion_mode=diffusion_mode, seed=seed)
     return out[0].detach().cpu().numpy()
+
+
+def load_style(source) -> torch.Tensor:
+    """The writer-style features of a prompt, [1,S,1280]: a tensor / array, or a file holding one (.npy, or .pt read with
+    weights_only=True).  The reference computes them from a handwriting image with torchvision's pretrained MobileNetV2
+    (text_style.py:43-59); that front end is not part of this build, so an image path is an error here."""
+    if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
+        path = str(source)
+        if path.endswith(".npy"):
+            source = np.load(path, allow_pickle=False)
+        elif path.endswith((".pt", ".pth")):
+            source = torch.load(path, map_location="cpu", weights_only=True)
+        else:
+            raise ValueError(f"{path}: pass the style features ([S,1280], .npy / .pt) — the StyleExtractor image front end is not built")
+    sv = torch.as_tensor(source, dtype=torch.float32)
+    if sv.dim() == 2:
+        sv = sv[None]
+    if sv.dim() != 3 or sv.shape[0] != 1 or sv.shape[2] != 1280:
+        raise ValueError(f"style features must be [S,1280] or [1,S,1280], got {tuple(sv.shape)}")
+    return sv
+
+
+def infer_file(prompt: str, source, config_path: str | None = None, checkpoint_path: str | None = None,
+               experiment_path: str | None = None, output: str = "result", diffusion_mode: str = "new", *, precision: str = "bf16",
+               seed: int = 0, render: bool = True) -> np.ndarray:
+    """The reference's command-line entry (inference.py:19-27) around this build's sampler: resolve config / checkpoint
+    (directly or inside ``experiment_path``), load the model, sample one prompt, write ``./<output>.png``.
+    Returns the [L,3] strokes."""
+    from .checkpoint import find_checkpoint, load_model
+    from .vis import show_strokes
+
+    if experiment_path:
+        from pathlib import Path
+        if not config_path:
+            config_path = str(Path(experiment_path) / "config.yml")
+        if not checkpoint_path:
+            ckpt = find_checkpoint(experiment_path)
+            checkpoint_path = str(ckpt) if ckpt else None
+    if not config_path or not checkpoint_path:
+        raise ValueError("Both config_path and checkpoint_path must be provided, either directly or via experiment_path.")
+    style = load_style(source)
+    model = load_model(config_path, checkpoint_path, precision=precision, max_B=1, style_rows=style.shape[1])
+    strokes = infer(prompt, style, model, diffusion_mode=diffusion_mode, seed=seed)
+    if render:
+        show_strokes(strokes, scale=1, name=output, show_output=False)
+    return strokes

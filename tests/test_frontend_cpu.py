@@ -1,0 +1,81 @@
+"""Front end around the sampler: checkpoint + config resolution and the stroke -> polyline output
+side.  CPU only: nothing here needs the HIP library beyond constructing the (lazy) model object."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dhg_amd
+from dhg_amd import spec
+
+
+def _sd(nl=2):
+    return {k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(nl).items()}
+
+
+@pytest.mark.parametrize("wrap", ["bare", "state_dict", "module_prefix"])
+def test_checkpoint_formats_of_the_reference_are_read(tmp_path, wrap):
+    sd = _sd()
+    obj = {"bare": sd, "state_dict": {"state_dict": sd, "meta": {"iter": 7}},
+           "module_prefix": {"state_dict": {"module." + k: v for k, v in sd.items()}}}[wrap]
+    f = tmp_path / "model_final.pth"
+    torch.save(obj, f)
+    got = dhg_amd.read_state_dict(f)
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_checkpoint_without_a_dict_is_rejected(tmp_path):
+    f = tmp_path / "x.pth"
+    torch.save(torch.zeros(3), f)
+    with pytest.raises(RuntimeError, match="No state_dict"):
+        dhg_amd.read_state_dict(f)
+
+
+def test_checkpoint_discovery_order(tmp_path):
+    assert dhg_amd.find_checkpoint(tmp_path) is None
+    for name in ("checkpoint_900.pth", "checkpoint_10000.pth", "checkpoint_last.pth"):
+        (tmp_path / name).write_bytes(b"")
+    assert dhg_amd.find_checkpoint(tmp_path).name == "checkpoint_10000.pth"      # numeric, not lexicographic
+    (tmp_path / "model_last.pth").write_bytes(b"")
+    assert dhg_amd.find_checkpoint(tmp_path).name == "model_last.pth"
+    (tmp_path / "model_final.pth").write_bytes(b"")
+    assert dhg_amd.find_checkpoint(tmp_path).name == "model_final.pth"
+
+
+def test_config_maps_to_model_dims_and_strict_load(tmp_path):
+    cfg = tmp_path / "config.yml"
+    cfg.write_text("training_args:\n  att_layers_num: 2\n  channels: 128\n  dropout: 0.0\n")
+    assert dhg_amd.read_config(cfg) == {"num_layers": 2, "c1": 128, "c2": 192, "c3": 256, "drop_rate": 0.0}
+    ck = tmp_path / "model_final.pth"
+    torch.save({"state_dict": _sd(2)}, ck)
+    m = dhg_amd.load_model(cfg, ck)
+    assert m.num_layers == 2 and not m.training
+    assert torch.equal(m.state_dict()["enc1.conv1.weight"], _sd(2)["enc1.conv1.weight"])
+    m2 = dhg_amd.load_model(None, ck)                      # layer count read off the checkpoint's keys
+    assert m2.num_layers == 2
+    torch.save({"state_dict": _sd(4)}, ck)                 # config says 2 attention layers, checkpoint has 4
+    with pytest.raises(RuntimeError, match="att_layers"):
+        dhg_amd.load_model(cfg, ck)
+
+
+def test_infer_file_argument_errors_mirror_the_reference(tmp_path):
+    with pytest.raises(ValueError, match="config_path and checkpoint_path"):
+        dhg_amd.infer_file("abc", np.zeros((14, 1280), np.float32))
+    with pytest.raises(ValueError, match="config_path and checkpoint_path"):
+        dhg_amd.infer_file("abc", np.zeros((14, 1280), np.float32), experiment_path=str(tmp_path))   # empty directory
+    with pytest.raises(ValueError, match="StyleExtractor"):
+        dhg_amd.load_style("writer.tif")
+    with pytest.raises(ValueError, match="style features"):
+        dhg_amd.load_style(np.zeros((14, 100), np.float32))
+    f = tmp_path / "style.npy"
+    np.save(f, np.ones((14, 1280), np.float32))
+    assert tuple(dhg_amd.load_style(str(f)).shape) == (1, 14, 1280)
+
+
+def test_strokes_to_polylines_follows_the_reference_plot_loop():
+    s = np.array([[1, 0, 0], [1, 0, 0], [0, 1, 0.9], [1, 0, 0.2], [1, 1, 0], [0, 0, 1], [2, 0, 0]], np.float32)
+    lines = dhg_amd.strokes_to_polylines(s)
+    # pen-up at rows 2 and 5: the stretch before row 2, then rows 2..4; the tail after the last lift is not drawn (vis.py:19-31)
+    assert [l.tolist() for l in lines] == [[[1, 0], [2, 0]], [[2, 1], [3, 1], [4, 2]]]
+    assert dhg_amd.strokes_to_polylines(np.zeros((4, 3), np.float32)) == []

@@ -333,3 +333,28 @@ def test_long_sequence_config_matches_oracle():
     outb = dhg_amd.sample(mb, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=T,
                           noise=noise.cuda()).cpu()
     assert torch.isfinite(outb).all() and (outb - ref).abs().max().item() < 0.1
+
+
+def test_infer_file_end_to_end(tmp_path, monkeypatch):
+    """The reference's command-line path (inference.py:19-96) around the HIP sampler: experiment directory -> config +
+    newest checkpoint -> model -> one prompt -> strokes (+ PNG when matplotlib is there)."""
+    (tmp_path / "config.yml").write_text("training_args:\n  att_layers_num: 2\n  channels: 128\n  dropout: 0.0\n")
+    torch.save({"state_dict": {"module." + k: v for k, v in _sd(2).items()}}, tmp_path / "checkpoint_2000.pth")
+    torch.save({"state_dict": _sd(4)}, tmp_path / "checkpoint_100.pth")          # older, different shape: must not be picked
+    style = spec.synthetic_inputs(1, 8, 1, seed=9)["style"][0]
+    np.save(tmp_path / "style.npy", style)
+    monkeypatch.chdir(tmp_path)
+    try:
+        import matplotlib  # noqa: F401
+        render = True
+    except ImportError:
+        render = False
+    prompt = "Follow the White Rabbit"
+    strokes = dhg_amd.infer_file(prompt, str(tmp_path / "style.npy"), experiment_path=str(tmp_path), output="res", seed=3, render=render)
+    assert strokes.shape == (392, 3) and np.isfinite(strokes).all()           # 24 tokens -> 16 per token, next multiple of 8
+    assert not render or (tmp_path / "res.png").stat().st_size > 0
+    m = dhg_amd.DiffusionModel(2, precision="bf16", max_B=1, max_L=392, max_Lt=24).eval()
+    m.load_state_dict(_sd(2))
+    ids = torch.tensor([dhg_amd.Tokenizer().encode(prompt)])
+    ref = dhg_amd.sample(m, ids.cuda(), torch.from_numpy(style)[None].cuda(), L=392, seed=3).cpu().numpy()[0]
+    assert np.array_equal(strokes, ref)
