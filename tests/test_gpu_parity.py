@@ -358,3 +358,23 @@ def test_infer_file_end_to_end(tmp_path, monkeypatch):
     ids = torch.tensor([dhg_amd.Tokenizer().encode(prompt)])
     ref = dhg_amd.sample(m, ids.cuda(), torch.from_numpy(style)[None].cuda(), L=392, seed=3).cpu().numpy()[0]
     assert np.array_equal(strokes, ref)
+
+
+@pytest.mark.parametrize("B,L,Lt,T", [(1, 8, 1, 2), (5, 136, 7, 2), (130, 64, 3, 2), (96, 488, 30, 1), (40, 1000, 62, 1)])
+def test_shape_sweep_bf16_tracks_the_fp32_path(B, L, Lt, T):
+    """Batch / length combinations that make the launchers pick every row-tile variant (16/32/64-row EncoderLayer tiles,
+    46/62/126-row ConvBlock tiles, chained and unchained enc_bc, one or several workgroup rounds): the fused bf16 path
+    must track this library's own fp32 path (itself pinned to the reference by the goldens) on the same inputs."""
+    inp = spec.synthetic_inputs(B, L, Lt, seed=100 + B, T=T)
+    tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        m = dhg_amd.DiffusionModel(2, precision=prec, max_B=B, max_L=L, max_Lt=Lt).eval()
+        m.load_state_dict(_sd(2))
+        outs[prec] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
+        del m
+    ref, got = outs["fp32"], outs["bf16"]
+    assert torch.isfinite(got).all()
+    scale = ref[..., :2].abs().max().item()
+    assert (got[..., :2] - ref[..., :2]).abs().max().item() < 0.03 * scale      # bf16 weights / activations, T <= 2 steps
+    assert (got[..., 2] - ref[..., 2]).abs().max().item() < 0.05
