@@ -69,8 +69,12 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int tiles = (p.L + BMO - 1) / BMO;
-  const int b = blockIdx.x / tiles;
-  const int m0 = (blockIdx.x % tiles) * BMO;
+  // XCD-aware workgroup id, the same sample -> XCD assignment in every fused kernel of the model: a sample's activations
+  // are then handed from kernel to kernel inside one XCD's L2 (measured: a 98 KB tile written by the previous kernel on
+  // the same XCD is read in 1.6 us, from another XCD in 3.8 us — tools/bench_handoff.cpp)
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = bid / tiles;
+  const int m0 = (bid % tiles) * BMO;
   const int Cin = p.Cin;
 
   const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = tile_stride<T>(CO);
