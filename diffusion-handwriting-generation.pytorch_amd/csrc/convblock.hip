@@ -58,8 +58,12 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   constexpr int T1 = C1 / 16, T2 = CO / 16;                                   // 16-channel tiles per stage
   constexpr int WN1 = NW == 8 ? (T1 >= 8 ? 8 : (T1 == 6 ? 6 : 4)) : 2;
   constexpr int WM1 = NW == 8 ? (T1 >= 6 ? 1 : 2) : 2;
-  constexpr int WN2 = NW == 8 ? (T2 % 8 == 0 ? 8 : 6) : 4;
-  constexpr int WM2 = 1;
+  // Per k-chunk a workgroup issues 4 (BM/16)(N/16) MFMA-cycles, reads WN (BM/16) KB of activation fragments from LDS
+  // (128 B/clk) and WM (N/16) KB of weight fragments through L1 (64 B/clk).  126-row tiles of the 128-channel blocks with
+  // 1 x 8 waves are LDS-bound (512 vs 256 cycles); 2 row groups x 4 channel groups balance all three at 256.
+  constexpr bool TALL = NW == 8 && BM >= 128 && T2 == 8;
+  constexpr int WN2 = NW == 8 ? (TALL ? 4 : (T2 % 8 == 0 ? 8 : 6)) : 4;
+  constexpr int WM2 = TALL ? 2 : 1;
   constexpr int MT1 = BM / WM1 / 16, NT1 = T1 / WN1;
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
