@@ -110,13 +110,13 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     // h rows [m0-3, m0-3+RH) are staged where h1/h2 will live later; the up-sampled low rows go straight into the XR
     // tile, and the GEMM epilogue adds the convolution in place (same lane reads and writes an element).
     constexpr int RXP = (RX + 15) / 16 * 16, RH = RXP + 2, MTU = RXP / 16;
-    constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 6, NTU = TU / WNU;
+    constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 4, NTU = TU / WNU;   // (12 tiles: 4 waves, one per SIMD, 3 tiles each)
     static_assert(NTU * WNU == TU && NW == 8, "unsupported input width");
     const bool actu = wave < WNU;
     const int ntu0 = (actu ? wave : 0) * NTU, nu = ntu0 * 16 + 4 * g;
     const int Ch = p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);
     char* HS = H1;
-    WRing<T, NTU, RING> ringu;
+    WRing<T, NTU, (NTU * MTU >= 24 ? 12 : RING)> ringu;
     Epi<NTU> epu;
     if (actu) {
       ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
