@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
     }
     STAMP(18);
-    layernorm_rows<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    layernorm_rows_1pass<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
     if (act) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < MT; ++j)
         acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
   }
-  layernorm_rows<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
+  layernorm_rows_1pass<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
   // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
   if (act) {
 #pragma unroll

@@ -179,3 +179,37 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] - mean[j]) * rstd[j];
 }
+
+// One-barrier form for the bf16 kernels: per-wave partial sums of x and x^2 go out together and var = E[x^2] - mean^2
+// (fp32; the rows are O(1) residual-stream values over 192-384 channels, so the cancellation costs ~1e-6 relative, far
+// below the bf16 rounding of the result).  Saves one LDS round trip + barrier per LayerNorm.
+template <int MT, int NT, int WN, int ROWS>
+DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true) {
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s += acc[i][j][r]; q += acc[i][j][r] * acc[i][j][r]; }
+    s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    if (g == 0 && act) {
+      red[wn * ROWS + row0 + j * 16 + l15] = s;
+      red[(WN + wn) * ROWS + row0 + j * 16 + l15] = q;
+    }
+  }
+  lds_barrier();
+  const float invn = 1.0f / (float)N;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) { s += red[w * ROWS + row0 + j * 16 + l15]; q += red[(WN + w) * ROWS + row0 + j * 16 + l15]; }
+    const float mean = s * invn;
+    const float rstd = rsqrtf(fmaxf(q * invn - mean * mean, 0.f) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i][j] = (acc[i][j] - mean) * rstd;
+  }
+}
