@@ -165,7 +165,8 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
           attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, trow,
                                      p.Lt, mr[u], lr[u], o[u]);
       }
-      lds_barrier();   // the staging tiles are rewritten by the next block
+      if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
+                                             // barrier behind the a1 store below does)
     }
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
       if (kb < 3 * KBS) STAMP(27 + 2 * (kb / KBS));
-      lds_barrier();   // the staging tiles are rewritten by the next block
+      if (kb + KBS < p.Lk) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
+                                             // barrier behind the a2 store below does)
     }
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
