@@ -166,7 +166,6 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         }
     }
     STAMP(12);
-    lds_barrier();   // HS (aliasing h1) is rewritten just below
   } else if (p.strokes) {
     // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load
     const int cpr = Cin / 4;   // 4 channels per item
@@ -214,10 +213,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
       }
     }
   }
-  // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
-  for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
-    *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
-  lds_barrier();
+  lds_barrier();   // x tiles complete (and the staged skip rows, which overlay h1, consumed)
   STAMP(1);
 
   WRing<T, NT2, RING> ring2;
@@ -246,6 +242,9 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
           store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
         }
     }
+    // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
+    for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
+      *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   }
   lds_barrier();
   STAMP(3);

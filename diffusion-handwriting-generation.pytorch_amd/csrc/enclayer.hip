@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ring.template run<MT>(acc2, op3, S, KC);
       if (hh == 0) ring.fill(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane, KC);   // FFN half 1
     }
-    lds_barrier();   // R3 is rewritten by the next half
+    if (hh == 0) lds_barrier();   // R3 is rewritten by the next half (after the last one the LayerNorm barrier below does)
     STAMP(21 + 2 * hh);
   }
   if (act) {
