@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/dhw.h"
+#include "xcd_swizzle.h"
 #include "../../include/dhw_debug.h"
 #include "dhw_kernels.h"
 
@@ -1535,6 +1536,8 @@ int64_t dhw_debug_read(dhw_handle* h, const char* name, float* host_dst, int64_t
   }
   return n;
 }
+
+int dhw_debug_xcd_swizzle(int block_id, int nwg) { return xcd_swizzle(block_id, nwg); }
 
 int dhw_profile_enable(dhw_handle* h, int on) {
   if (!h) return DHW_ERR_ARG;

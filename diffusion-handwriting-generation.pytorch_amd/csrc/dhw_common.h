@@ -95,13 +95,7 @@ DHW_DEV void store4(bf16_t* p, const f32x4& v) {
 }
 DHW_DEV void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// XCD-aware workgroup id: the dispatcher deals consecutive blockIdx round-robin over the 8 XCDs (private L2 each), so
-// the workgroups that share data (the row tiles of one sample read the same K/V) would each miss in a different L2.
-// This bijection hands every XCD a contiguous range of logical ids instead (any grid size).
-DHW_DEV int xcd_swizzle(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
+#include "xcd_swizzle.h"
 
 // Cooperative global -> LDS copy of `total` 16-byte pieces: piece id -> source pointer (null = zero fill) and LDS
 // destination.  U loads are issued back to back before the first store, so a thread pays the L2 / Infinity-Cache latency

@@ -33,6 +33,10 @@ int dhw_set_streams(dhw_handle*, int n);
 /* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
 int dhw_set_graph(dhw_handle*, int on);
 
+/* The logical workgroup id the fused kernels derive from blockIdx (csrc/dhw_common.h xcd_swizzle): a bijection of
+ * [0, nwg) that gives each of the 8 XCDs a contiguous id range.  Host-side copy for tests; needs no device. */
+int dhw_debug_xcd_swizzle(int block_id, int nwg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,3 +124,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src and "/root/reference" not in src, f
+
+
+def test_xcd_swizzle_is_a_bijection_with_contiguous_ranges_per_xcd():
+    """Every fused kernel derives (sample, row tile) from this id: it must visit each tile exactly once for any grid,
+    and the blocks the dispatcher deals to one XCD (blockIdx % 8) must get one contiguous id range."""
+    f = _lib.lib().dhw_debug_xcd_swizzle
+    for nwg in (1, 2, 7, 8, 9, 15, 64, 100, 192, 255, 256, 257, 1001):
+        ids = [f(i, nwg) for i in range(nwg)]
+        assert sorted(ids) == list(range(nwg)), nwg
+        for x in range(min(8, nwg)):
+            mine = sorted(ids[i] for i in range(x, nwg, 8))
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (nwg, x)
