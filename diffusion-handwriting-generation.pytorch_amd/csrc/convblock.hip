@@ -11,7 +11,10 @@
 // the current stage's epilogue (gemm_core.h).  The output tile goes through LDS so global stores are whole
 // coalesced rows (+ the AvgPool1d side output).  Replaces three launches and the HBM/L2 round trips of h1/h2.
 //
-// bf16: 8 waves (2 per SIMD), BM = 64.  fp32 (parity mode): 4 waves, BM = 32 (LDS budget).
+// bf16: 8 waves (2 per SIMD), 62-row tiles (126 at full resolution, 46 at the L/4 level: launch_convblock).  fp32 (parity
+// mode): 4 waves, 30-row tiles (LDS budget).  Decoder blocks (UPC) evaluate Upsample(low) + skip_conv(h) (model.py:169-175)
+// as one more 3-tap GEMM stage in front; dec1 evaluates the eps / pen heads and the scheduler step from its fp32 tile;
+// CH = 1 continues into the next EncoderLayer's first half on the output tile (enc_a_core.h; off by default).
 #include <algorithm>
 #include <cstdlib>
 #include "enc_a_core.h"

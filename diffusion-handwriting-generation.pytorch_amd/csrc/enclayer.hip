@@ -1,15 +1,18 @@
 // enclayer.hip — the stroke side of one EncoderLayer (reference model.py:37-58) in TWO launches instead of
-// eight.  A workgroup (8 waves) owns 64 stroke rows of one sample; every intermediate of its rows lives in
-// LDS.  The only hand-off through global memory is the one the algorithm forces: self-attention needs the
-// K/V of ALL rows of the sample, so the layer is cut between the q/k/v projection and the attention.
+// eight.  A workgroup (8 waves) owns 64 / 32 / 16 stroke rows of one sample (pick_bm: enough tiles for every CU);
+// every intermediate of its rows lives in LDS.  The only hand-off through global memory is the one the algorithm
+// forces: self-attention needs the K/V of ALL rows of the sample, so the layer is cut between the q/k/v projection
+// and the attention — and since everything between two self-attentions is row-local, enc_bc<NEXT> goes on with the
+// next layer's enc_a (enc5: via AvgPool1d + att_dense) on the tile it holds, so a chain of layers costs one launch each.
 //
 //   enc_a : q1 = Wq(x+PE) -> cross-attention over the text keys -> dense -> LN -> FiLM1 -> +x = x2
 //           -> [q2|k2|v2] = W(x2 (+PE))                       (writes x2, qk2, vt2)
 //   enc_bc: self-attention(q2,k2,v2) -> dense -> +x2 -> LN -> FiLM2 = x3 -> ffn1 (SiLU) -> ffn2 -> +x3
 //           -> LN -> FiLM3 = out (+ AvgPool1d(2) side output)
 //
-// GEMM stages: waves WM (row groups) x WN (channel groups), weights streamed from L2 in fragment order
-// (gemm_core.h).  Attention stages: wave = 16 rows x every second head (attn_core.h).
+// GEMM stages: every wave covers all rows and 1/WN of the channels (no two waves stream the same weights), weights
+// streamed from L2 in fragment order (gemm_core.h).  Attention stages: K/V blocks staged in LDS, wave = 16 rows x
+// one or two heads (attn_core.h).  Workgroup ids are XCD-aware (xcd_swizzle.h): a sample's tiles share one L2.
 #include <algorithm>
 #include <cstdlib>
 #include "enc_a_core.h"
