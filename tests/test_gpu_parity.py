@@ -378,3 +378,24 @@ def test_shape_sweep_bf16_tracks_the_fp32_path(B, L, Lt, T):
     scale = ref[..., :2].abs().max().item()
     assert (got[..., :2] - ref[..., :2]).abs().max().item() < 0.03 * scale      # bf16 weights / activations, T <= 2 steps
     assert (got[..., 2] - ref[..., 2]).abs().max().item() < 0.05
+
+
+def test_full_size_batch_matches_the_oracle_on_sampled_prompts():
+    """BASELINE configs[1] batch (B=64, L=488, Lt=30) with an 8-step schedule: the launch configuration of the bench
+    (126-row ConvBlock tiles, 16-row attention-level tiles, chained enc_bc -> enc_a, all-steps text plane) checked
+    directly against the oracle on three prompts of the batch."""
+    B, L, Lt, T = 64, 488, 30, 8
+    inp = spec.synthetic_inputs(B, L, Lt, seed=21, T=T)
+    tx, sv, nz = (torch.from_numpy(inp[k]) for k in ("text", "style", "noise"))
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        m = dhg_amd.DiffusionModel(2, precision=prec, max_B=B, max_L=L, max_Lt=Lt).eval()
+        m.load_state_dict(_sd(2))
+        outs[prec] = dhg_amd.sample(m, tx.cuda(), sv.cuda(), L=L, T=T, noise=nz.cuda()).cpu()
+        del m
+    for b in (0, 37, 63):
+        ref, _ = ref_cpu.sample(_sd(2), tx[b:b + 1], sv[b:b + 1], L, nz[:, b:b + 1], T=T)
+        scale = ref[..., :2].abs().max().item()
+        assert (outs["fp32"][b:b + 1] - ref).abs().max().item() < 1e-3, b
+        assert (outs["bf16"][b:b + 1, :, :2] - ref[..., :2]).abs().max().item() < 0.03 * scale, b
+        assert (outs["bf16"][b:b + 1, :, 2] - ref[..., 2]).abs().max().item() < 0.05, b
