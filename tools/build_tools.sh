@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds the micro-benchmarks under tools/ into tools/bin/ (git-ignored; the directory travels to the GPU box with gpurun).
+# Needs the library objects: python -c "import __graft_entry__ as g; g.build()" first.
+set -e
+cd "$(dirname "$0")/.."
+P="diffusion-handwriting-generation.pytorch_amd/build"
+H="hipcc --offload-arch=gfx950 -O2 -std=c++17"
+mkdir -p tools/bin
+$H -c tools/bench_conv.cpp -o tools/bin/bench_conv.o && hipcc --offload-arch=gfx950 tools/bin/bench_conv.o $P/convblock.o $P/enclayer.o -o tools/bin/bench_conv
+$H -c tools/bench_enc.cpp -o tools/bin/bench_enc.o && hipcc --offload-arch=gfx950 tools/bin/bench_enc.o $P/enclayer.o -o tools/bin/bench_enc
+$H -c tools/bench_text.cpp -o tools/bin/bench_text.o && hipcc --offload-arch=gfx950 tools/bin/bench_text.o $P/gemm.o -o tools/bin/bench_text
+for t in bench_l2 bench_copy bench_handoff bench_lat; do $H tools/$t.cpp -o tools/bin/$t; done
+echo "built: $(ls tools/bin | grep -v '\.o$' | tr '\n' ' ')"
