@@ -27,6 +27,11 @@ namespace {
     if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
+// Row stride of the h2 / output staging tile: the conflict-free operand padding, except for the 126-row tiles, where the
+// decoder block with the fused input stage would overflow LDS by 2 KB (128 channels with the 16-byte padding: one
+// 2-way conflict per 16 lanes).
+template <typename T, int BM> __host__ __device__ constexpr int h2_stride(int CO) { return BM >= 128 ? CO * (int)sizeof(T) + 16 : tile_stride<T>(CO); }
+
 template <int NT>
 struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles, requested before the main loop
   f32x4 bias[NT], gam[NT], bet[NT];
@@ -84,7 +89,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   const int m0 = (bid % tiles) * BMO;
   const int Cin = p.Cin;
 
-  const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = tile_stride<T>(CO);
+  const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = h2_stride<T, BM>(CO);
   char* XS = smem;                       // SiLU(x)   [RX][Cin]
   char* XR = XS + RX * SX;               // x         [RX][Cin]
   char* H1 = XR + RX * SX;               // h1        [BM+2][C1]  (index i <-> sample row m0-1+i)
@@ -347,7 +352,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
       m.QR = smem + BM * SH2;
       m.red = reinterpret_cast<float*>(m.QR + BM * SH2);
       m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
-      m.VT = m.KT + 32 * (CO * ES + 16);
+      m.VT = m.KT + 32 * tile_stride<T>(CO);
       m.VS = smem;
       enc_a_body<T, CO, BM, 4>(nx.a, m, b, m0, rows_valid);   // (tile starts are multiples of BM - 2: even, not 8-aligned)
     }
@@ -358,7 +363,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
 template <typename T, int BM, int CO>
 size_t lds_bytes(int Cin, int up_cin = 0) {
   const size_t xt = (size_t)2 * (BM + 2) * tile_stride<T>(Cin);
-  const size_t ops = xt + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * tile_stride<T>(CO);
+  const size_t ops = xt + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * h2_stride<T, BM>(CO);
   const size_t outf = (size_t)BM * (CO * 4 + 16);
   const size_t up = up_cin ? xt + (size_t)((BM + 2 + 15) / 16 * 16 + 2) * tile_stride<T>(up_cin) : 0;   // x tiles + staged h rows
   return std::max(ops, std::max(outf, up));

@@ -64,7 +64,7 @@ struct EncALds {
   char* VS;
 };
 template <typename T, int DM, int BM>
-constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * (DM * sizeof(T) + 16) + (size_t)DM * (32 * sizeof(T) + 16); }
+constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + 16); }
 
 // enc_a for the BM-row tile [m0, m0+BM) of sample b, of which the first rows_valid rows are this workgroup's to write.
 // p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
@@ -104,7 +104,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   }
   if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
   // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
-  constexpr int KBC = 32, SKC = DM * ES + 16, SVC = KBC * ES + 16;
+  constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + 16;
   char* KT = m.KT;
   char* VT = m.VT;
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;

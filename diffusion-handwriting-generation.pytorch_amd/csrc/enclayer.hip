@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   m.QR = m.XR + BM * S;
   m.red = reinterpret_cast<float*>(m.QR + BM * S);
   m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
-  m.VT = m.KT + 32 * (DM * sizeof(T) + 16);
+  m.VT = m.KT + 32 * tile_stride<T>(DM);
   m.VS = smem;   // spans the x2 and q1 tiles: DM * (BM * ES + 16) <= 2 * BM * S
   enc_a_body<T, DM, BM>(p, m, b, m0, min(BM, p.Lk - m0));
 }
@@ -43,11 +43,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // x3 / FFN tiles, which are written only after the attention), else 64
 template <typename T, int DM, int BM>
 constexpr int self_kbs() {
-  return (size_t)BM * (DM * sizeof(T) + 16) + (size_t)128 * (DM * sizeof(T) + 16) + (size_t)DM * (128 * sizeof(T) + 16) <= 160 * 1024 ? 128 : 64;
+  return (size_t)BM * tile_stride<T>(DM) + (size_t)128 * tile_stride<T>(DM) + (size_t)DM * (128 * sizeof(T) + 16) <= 160 * 1024 ? 128 : 64;
 }
 template <typename T, int DM, int BM>
 constexpr size_t lds_bc_bytes() {
-  constexpr size_t S = DM * sizeof(T) + 16, KBS = self_kbs<T, DM, BM>();
+  constexpr size_t S = tile_stride<T>(DM), KBS = self_kbs<T, DM, BM>();
   constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = BM * S + KBS * S + DM * (KBS * sizeof(T) + 16);
   return stages > att ? stages : att;
 }
@@ -55,7 +55,7 @@ constexpr size_t lds_bc_bytes() {
 // NEXT: 0, or the EncChain mode compiled into this variant (DN = width of the chained layer)
 template <typename T, int DM, int BM, int NEXT>
 constexpr size_t lds_bc_chain_bytes() {
-  constexpr size_t S = DM * sizeof(T) + 16, base = 3 * BM * S + 2 * 8 * BM * sizeof(float);
+  constexpr size_t S = tile_stride<T>(DM), base = 3 * BM * S + 2 * 8 * BM * sizeof(float);
   constexpr size_t chain = NEXT == 1 ? base + enc_a_text_kv_bytes<T, DM, BM>() : NEXT == 2 ? base + enc_a_text_kv_bytes<T, 384, BM / 2>() : 0;
   return chain > lds_bc_bytes<T, DM, BM>() ? chain : lds_bc_bytes<T, DM, BM>();
 }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[40] = __builtin_amdgcn_s_memtime();
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
-    constexpr int SK = DM * ES + 16, SV = KBS * ES + 16;
+    constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + 16;
     char* KT = R2;
     char* VT = KT + KBS * SK;
     const int rg = wave % RG, hs = wave / RG;
@@ -253,12 +253,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     EncALds m;
     m.XR = R3; m.QR = R1; m.red = red;
     m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
-    m.VT = m.KT + 32 * (DM * ES + 16);
+    m.VT = m.KT + 32 * tile_stride<T>(DM);
     m.VS = R1;
     enc_a_body<T, DM, BM>(nx.a, m, b, m0, rows_valid);
   } else if constexpr (NEXT == 2) {
     // AvgPool1d(2) of the out tile -> R1; Linear DM -> DN (att_dense) -> x tile of the first attention layer; its enc_a
-    constexpr int DN = 384, BN2 = BM / 2, SN = DN * ES + 16, NTN = DN / 8 / 16, MTN = BN2 / 16;
+    constexpr int DN = 384, BN2 = BM / 2, SN = tile_stride<T>(DN), NTN = DN / 8 / 16, MTN = BN2 / 16;
     {
       constexpr int EPV = 16 / ES;
       const int cpr = DM / EPV;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     EncALds m;
     m.XR = XN; m.QR = XN + BN2 * SN; m.red = red;
     m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
-    m.VT = m.KT + 32 * (DN * ES + 16);
+    m.VT = m.KT + 32 * tile_stride<T>(DN);
     m.VS = XN;
     enc_a_body<T, DN, BN2>(nx.a, m, b, m02, rows2);
   }
@@ -313,8 +313,8 @@ hipError_t launch_bc(const EncLayerParams& p, const EncChain& nx, hipStream_t st
 
 // variants with a compiled chain: mode 1 for the attention layers (DM = 384, tiles up to 32 rows: LDS), mode 2 for enc5
 template <typename T, int DM, int BM>
-constexpr bool has_chain(int mode) {
-  return (mode == 1 && DM == 384 && BM <= 32) || (mode == 2 && DM == 256 && BM >= 32);
+constexpr bool has_chain(int mode) {   // (LDS: the chained layer's text K/V block sits behind the three stage tiles)
+  return (mode == 1 && DM == 384 && BM <= 32) || (mode == 2 && DM == 256 && BM == 32);
 }
 
 template <typename T, int DM, int BM>
@@ -372,7 +372,7 @@ int pick_bm(int B, int Lk, int bm_min = 0) {
   // LDS budget (160 KiB) of enc_bc: the three stage tiles, or the a2 tile + one 64-key K/V block; shrink the row tile until it fits
   auto lds_bc = [](int m) {
     return std::max((size_t)3 * m * tile_stride<T>(DM) + 2 * 8 * m * sizeof(float),
-                    (size_t)m * tile_stride<T>(DM) + (size_t)64 * (DM * sizeof(T) + 16) + (size_t)DM * (64 * sizeof(T) + 16));
+                    (size_t)m * tile_stride<T>(DM) + (size_t)64 * tile_stride<T>(DM) + (size_t)DM * (64 * sizeof(T) + 16));
   };
   while (bm > 16 && lds_bc(bm) > 160 * 1024) bm /= 2;
   if (DM % 128 != 0 && bm < 32) bm = 32;
@@ -409,7 +409,7 @@ bool enclayer_supported(int prec, int d, int heads) {
 bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_next) {
   if (prec != PREC_BF16) return false;
   if (mode == 1) return d == 384 && d_next == 384 && pick_bm<bf16_t, 384>(B, Lk) <= 32;
-  if (mode == 2) return d == 256 && d_next == 384 && (Lk & 1) == 0;   // (with bm_min = 32)
+  if (mode == 2) return d == 256 && d_next == 384 && (Lk & 1) == 0 && pick_bm<bf16_t, 256>(B, Lk, 32) == 32;   // (with bm_min = 32)
   return false;
 }
 

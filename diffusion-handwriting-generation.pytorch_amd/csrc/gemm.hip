@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
     lds_stride[s] = 0;
     if (s < p.nseg) {
       const int rows = BM + (p.seg[s].taps == 3 ? 2 : 0);
-      lds_stride[s] = p.seg[s].C * ES + 16;
+      lds_stride[s] = tile_stride<T>(p.seg[s].C);
       off += rows * lds_stride[s];
     }
   }
@@ -310,7 +310,7 @@ hipError_t launch_one(const GemmParams& p, hipStream_t st) {
   dim3 grid(p.B * tiles, p.N / BN);
   size_t lds = 0;
   for (int s = 0; s < p.nseg; ++s)
-    lds += (size_t)(BM + (p.seg[s].taps == 3 ? 2 : 0)) * (p.seg[s].C * sizeof(T) + 16);
+    lds += (size_t)(BM + (p.seg[s].taps == 3 ? 2 : 0)) * tile_stride<T>(p.seg[s].C);
   lds += 2 * WN * BM * sizeof(float);
   const size_t out_tile = std::max((size_t)BM * (BN * (p.out_f32 ? 4 : sizeof(T)) + 16), p.n_store < p.N ? (size_t)BN * (BM * sizeof(T) + 16) : 0);
   lds = std::max(lds, out_tile);
