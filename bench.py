@@ -177,7 +177,7 @@ def kernel_profile(model, one_step):
     return roof, table
 
 
-PMC_FILE = "r01_v8_hbm_traffic_pmc.json"
+PMC_FILE = "r01_v9_hbm_traffic_pmc.json"
 
 
 def pmc_traffic(label):
