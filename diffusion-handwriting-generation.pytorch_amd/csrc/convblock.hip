@@ -107,10 +107,6 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   STAMP(0);
   WRing<T, NT1, RING> ring1;
   Epi<NT1> ep1;
-  if (UPC == 0 && act1) {
-    ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during staging
-    ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
-  }
 
   // ---- stage 0: x tile -> LDS (raw + SiLU), zero outside the sample ('same' padding)
   if constexpr (UPC != 0) {
@@ -126,10 +122,6 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     char* HS = H1;
     WRing<T, NTU, (NTU * MTU >= 24 ? 12 : RING)> ringu;
     Epi<NTU> epu;
-    if (actu) {
-      ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
-      epu.load(p.up_b, nullptr, nullptr, nu);
-    }
     {
       const int cpr = Ch * ES / 16, cpx = Cin * ES / 16;
       const char* src = reinterpret_cast<const char*>(p.up_h);
@@ -142,6 +134,10 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
           [&](int id) { const int r = id / cpx, cc = id - r * cpx, lrow = m0 - 2 + r;
                         return lrow >= 0 && lrow < p.L ? reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * Cin) * ES + (size_t)cc * 16) : nullptr; },
           [&](int id) { const int r = id / cpx, cc = id - r * cpx; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); });
+    }
+    if (actu) {   // (requested behind the staging loads: see below)
+      ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
+      epu.load(p.up_b, nullptr, nullptr, nu);
     }
     lds_barrier();
     STAMP(10);
@@ -220,6 +216,12 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         *reinterpret_cast<uint4*>(XS + dst[u]) = v[u];
       }
     }
+  }
+  // the first stage's weights are requested BEHIND the staging loads (a wave's loads complete in order and the L1 miss
+  // queue is shared: a 24 KB-per-wave prefetch in front of them delays the tile everything waits for)
+  if (UPC == 0 && act1) {
+    ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);
+    ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
   }
   lds_barrier();   // x tiles complete (and the staged skip rows, which overlay h1, consumed)
   STAMP(1);

@@ -98,10 +98,6 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   WRing<T, NT> ring;
   EpiParams<NT> ep;
   ENC_STAMP(0);
-  if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);   // the q1 weights fly while x is staged
-    ep.load(p.b_q1, nullptr, nullptr, n0);
-  }
   if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
   // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
   constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + 16;
@@ -110,6 +106,12 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
   attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
+  // the q1 weights are requested BEHIND the staging loads: a wave's loads complete in order and the L1 miss queue is
+  // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
+  if (act) {
+    ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);
+    ep.load(p.b_q1, nullptr, nullptr, n0);
+  }
   lds_barrier();
   ENC_STAMP(1);
 
