@@ -121,9 +121,11 @@ DHW_DEV void attn_wave16_auto(const Frag<T> (&qf)[(D + 31) / 32], const T* krow,
 // (16 rows x 1 head) unit lives in the caller's registers across blocks.
 //   kt : LDS address of K tile row (lane&15), this head's first channel
 //   vt : LDS address of V^T tile row (head channel lane&15), key 4*(lane>>4)
+//   padbits: bit 4t+r set = this lane's key kb + 16t + 4*(lane>>4) + r is a padded text token (score += -1e9); the caller
+//            reads the mask ahead of time (attn_pad_bits) so no global load sits in the softmax
 template <typename T, int D, int KB>
 DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, int SK, const char* vt, int SV, int kb,
-                            const int64_t* trow, int Lk, float& m_run, float& l_run, f32x4 (&o)[D / 16]) {
+                            unsigned padbits, int Lk, float& m_run, float& l_run, f32x4 (&o)[D / 16]) {
   constexpr int ES = sizeof(T), DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const float scale = rsqrtf((float)D);
@@ -146,7 +148,7 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
       const int key = kb + 16 * t + 4 * g + r;
       float v = s[t][r] * scale;
       if (key < Lk) {
-        if (trow && trow[key] == 0) v += -1e9f;   // attention.py:44
+        if ((padbits >> (4 * t + r)) & 1u) v += -1e9f;   // attention.py:44
       } else {
         v = -INFINITY;
       }
@@ -181,6 +183,30 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
     }
   }
 }
+
+// This lane's slice of the key-padding mask of the KB-key block at kb (trow: the sample's token ids, 0 = pad; null = no
+// mask): load() only requests the token ids, bits() turns them into the padbits word where it is first needed, so the
+// loads are in flight across whatever the caller does in between.
+template <int KB>
+struct PadMask {
+  int64_t tok[KB / 4];
+  DHW_DEV void load(const int64_t* trow, int kb, int Lk) {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int t = 0; t < KB / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 16 * t + 4 * g + r;
+        tok[4 * t + r] = (trow && key < Lk) ? trow[key] : 1;
+      }
+  }
+  DHW_DEV unsigned bits() const {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < KB / 4; ++i) m |= (tok[i] == 0 ? 1u : 0u) << i;
+    return m;
+  }
+};
 
 // cooperative copy of one key block into LDS: K rows [kb, kb+KB) x C channels from `ksrc` (row stride ldk elements,
 // already offset to the sample's first key row and first K channel) and V^T rows [0,C) x keys [kb, kb+KB) from `vsrc`

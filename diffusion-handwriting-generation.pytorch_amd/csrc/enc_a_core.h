@@ -106,6 +106,9 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
   attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
+  const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
+  PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
+  pad.load(trow, 0, p.Lt);
   // the q1 weights are requested BEHIND the staging loads: a wave's loads complete in order and the L1 miss queue is
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
@@ -154,8 +157,9 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
     }
-    const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
     for (int kb = 0; kb < p.Lt; kb += KBC) {
+      if (kb) pad.load(trow, kb, p.Lt);
+      const unsigned padbits = pad.bits();
       if (kb) {
         attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
@@ -164,7 +168,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
       for (int u = 0; u < UMAX; ++u) {
         const int h = hs + u * HS;
         if (h < H)
-          attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, trow,
+          attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, padbits,
                                      p.Lt, mr[u], lr[u], o[u]);
       }
       if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the

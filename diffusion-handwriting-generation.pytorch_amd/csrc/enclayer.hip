@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int sub = 0; sub < KBS; sub += 64)
             if (kb + sub < p.Lk)
               attn_block_lds<T, 64, 64>(qf[u], KT + (sub + l15) * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + (sub + 4 * g) * ES, SV,
-                                        kb + sub, nullptr, p.Lk, mr[u], lr[u], o[u]);
+                                        kb + sub, 0u, p.Lk, mr[u], lr[u], o[u]);
         }
       }
       if (kb < 3 * KBS) STAMP(27 + 2 * (kb / KBS));
