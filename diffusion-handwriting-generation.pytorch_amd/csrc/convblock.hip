@@ -75,7 +75,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   constexpr int MT1 = BM / WM1 / 16, NT1 = T1 / WN1;
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
-  constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / OCC;   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
+  constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,6 +395,8 @@ hipError_t convblock_init() {
   if ((e = attr<bf16_t, 128, 128, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 128, 8, 2>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8, 2>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 128, 4, 2>()) != hipSuccess) return e;
+  if ((e = attr<bf16_t, 64, 192, 4, 2>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
@@ -436,11 +438,15 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) 
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
         const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
+        if (getenv("DHW_CONV_NW") && atoi(getenv("DHW_CONV_NW")) == 4 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 128, 4, 2>(p, st);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 128, 8, 2>(p, st);
         return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
       }
       case 192:
+        if (getenv("DHW_CONV_NW") && atoi(getenv("DHW_CONV_NW")) == 4 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 192, 4, 2>(p, st);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 192, 8, 2>(p, st);
         return launch_t<bf16_t, 64, 192, 8>(p, st);
