@@ -55,6 +55,7 @@ SIGNATURES = {
     "dhw_set_graph": (C.c_int, [_P, C.c_int]),
     "dhw_debug_xcd_swizzle": (C.c_int, [C.c_int, C.c_int]),
     "dhw_set_streams": (C.c_int, [_P, C.c_int]),
+    "dhw_debug_randn": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 
 

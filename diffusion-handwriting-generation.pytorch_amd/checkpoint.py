@@ -45,10 +45,15 @@ def read_config(config_path: str | Path) -> dict:
 
     with open(config_path) as f:
         cfg = yaml.safe_load(f) or {}
-    ta = cfg.get("training_args") or {}
-    ch = int(ta.get("channels", 128))
-    return {"num_layers": int(ta.get("att_layers_num", 4)), "c1": ch, "c2": ch * 3 // 2, "c3": ch * 2,
-            "drop_rate": float(ta.get("dropout", 0.1))}
+    ta = cfg.get("training_args")
+    if not isinstance(ta, dict):
+        raise KeyError(f"{config_path}: no `training_args` section")
+    missing = [k for k in ("att_layers_num", "channels", "dropout") if k not in ta]
+    if missing:   # the reference reads cfg.training_args.<key> and fails on an incomplete config; it has no defaults
+        raise KeyError(f"{config_path}: training_args is missing {', '.join(missing)}")
+    ch = int(ta["channels"])
+    return {"num_layers": int(ta["att_layers_num"]), "c1": ch, "c2": ch * 3 // 2, "c3": ch * 2,
+            "drop_rate": float(ta["dropout"])}
 
 
 def load_model(config_path: str | Path | None = None, checkpoint_path: str | Path | None = None, *, precision: str = "bf16",

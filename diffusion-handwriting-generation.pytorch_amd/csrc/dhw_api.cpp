@@ -167,8 +167,16 @@ struct dhw_handle {
   int film_tot = 0;
   float *d_film_w = nullptr, *d_film_b = nullptr;
   float *d_sig32 = nullptr, *d_film = nullptr, *d_sigma_in = nullptr;
-  float *d_sig32_T = nullptr, *d_film_T = nullptr;
-  int film_T_cap = 0;
+  // dhw_sample: one FiLM table [T, 2*film_tot] per schedule length T, allocated once and never moved, so a cached graph
+  // for T keeps reading ITS table whatever other T values are sampled in between (a single shared, re-grown buffer let a
+  // replayed graph read another schedule's table).  d_film_T = the table of the call being enqueued.
+  struct FilmT {
+    float *d_sigma = nullptr, *d_sig32 = nullptr, *d_film = nullptr;
+    std::vector<float> h_sigma;   // source of the async upload: must outlive the call
+    bool ready = false;           // table computed for the current weights
+  };
+  std::map<int, FilmT> film_T;
+  float* d_film_T = nullptr;
 
   // small fp32 weights
   float *sg_w1, *sg_b1, *sg_w2, *sg_b2, *in_w, *in_b, *out_w, *out_b, *pen_w, *pen_b, *emb;
@@ -210,8 +218,6 @@ struct dhw_handle {
   float* d_noise_stage = nullptr;
   size_t noise_stage_cap = 0;
   uint64_t* d_seed = nullptr;   // [seed, first_sample] read by the noise kernels
-  float* d_sigma_T = nullptr;
-  int film_T_ready = 0;         // T for which d_film_T currently holds the FiLM table (0 = none)
 
   int last_B = 0, last_L = 0, last_Lt = 0;
 };
@@ -1035,14 +1041,14 @@ int check_shapes(dhw_handle* h, int B, int L, int Lt) {
   return 0;
 }
 
-int ensure_film_T(dhw_handle* h, int T) {
-  if (T <= h->film_T_cap) return 0;
+int ensure_film_T(dhw_handle* h, int T, dhw_handle::FilmT** out) {
+  dhw_handle::FilmT& ft = h->film_T[T];
+  *out = &ft;
+  if (ft.d_film) return 0;
   int rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_sigma_T, (size_t)T * 4))) return rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_sig32_T, (size_t)T * SIG * 4))) return rc;
-  if ((rc = dev_alloc(h, (void**)&h->d_film_T, (size_t)T * 2 * h->film_tot * 4))) return rc;
-  h->film_T_cap = T;
-  h->film_T_ready = 0;
+  if ((rc = dev_alloc(h, (void**)&ft.d_sigma, (size_t)T * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&ft.d_sig32, (size_t)T * SIG * 4))) return rc;
+  if ((rc = dev_alloc(h, (void**)&ft.d_film, (size_t)T * 2 * h->film_tot * 4))) return rc;
   return 0;
 }
 
@@ -1246,7 +1252,7 @@ int dhw_finalize(dhw_handle* h) {
     if ((rc = pack_enclayer(h, "att_layers." + std::to_string(i), dt, 6, 1.0f, d.max_L / 8, h->el[2 + i]))) return rc;   // model.py:104-109
   HIPCK(h, hipDeviceSynchronize());
   h->packed = true;
-  h->film_T_ready = 0;
+  for (auto& kv : h->film_T) kv.second.ready = false;
   return 0;
 }
 
@@ -1409,23 +1415,27 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if ((rc = dhw_finalize(h))) return rc;
   HIPCK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)hip_stream;
-  if ((rc = ensure_film_T(h, T))) return rc;
+  dhw_handle::FilmT* ft = nullptr;
+  if ((rc = ensure_film_T(h, T, &ft))) return rc;
+  h->d_film_T = ft->d_film;
   if (h->plane) {
     const int ns = std::min(h->nstreams, B), per = (B + ns - 1) / ns;
     for (int s = 0; s < ns; ++s)
       if ((rc = ensure_plane(h, h->ws[s], plane_chunk(T), per))) return rc;
   }
-  std::vector<float> beta, alpha, sig(T);
+  std::vector<float> beta, alpha;
   schedule_host(T, beta, alpha);
-  for (int i = 0; i < T; ++i) sig[i] = sqrtf(alpha[i]);   // inference.py:89
-  if (h->film_T_ready != T) {
-    // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]
-    HIPCK(h, hipMemcpy(h->d_sigma_T, sig.data(), T * 4, hipMemcpyHostToDevice));
-    Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, h->d_film_T, 0};
-    RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(h->d_sigma_T, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32_T, st));
-    RUN_SMALL(c, "film_table", launch_film(h->d_sig32_T, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film_T, st));
+  if (!ft->ready) {
+    // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]; uploaded on the caller's
+    // stream from a buffer the handle owns, so it is ordered against everything else this call enqueues
+    ft->h_sigma.resize(T);
+    for (int i = 0; i < T; ++i) ft->h_sigma[i] = sqrtf(alpha[i]);   // inference.py:89
+    HIPCK(h, hipMemcpyAsync(ft->d_sigma, ft->h_sigma.data(), T * 4, hipMemcpyHostToDevice, st));
+    Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, ft->d_film, 0};
+    RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(ft->d_sigma, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, ft->d_sig32, st));
+    RUN_SMALL(c, "film_table", launch_film(ft->d_sig32, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, ft->d_film, st));
     if (c.err) return c.err;
-    h->film_T_ready = T;
+    ft->ready = true;
   }
   {
     hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, st);
@@ -1538,6 +1548,19 @@ int64_t dhw_debug_read(dhw_handle* h, const char* name, float* host_dst, int64_t
 }
 
 int dhw_debug_xcd_swizzle(int block_id, int nwg) { return xcd_swizzle(block_id, nwg); }
+
+int dhw_debug_randn(dhw_handle* h, uint64_t seed, int64_t first_sample, int B, int L, int iter, float* host_dst) {
+  if (!h || !host_dst || B < 1 || L < 1 || iter < -1 || (long)B * L > (long)h->dims.max_B * h->dims.max_L)
+    return fail(h, DHW_ERR_ARG, "dhw_debug_randn: bad argument");
+  HIPCK(h, hipSetDevice(h->device));
+  HIPCK(h, hipDeviceSynchronize());
+  const long rows = (long)B * L;
+  hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, nullptr);
+  if (e == hipSuccess) e = launch_randn_init(h->ws[0].d_xt, rows, L, h->d_seed, 0, nullptr, iter);
+  if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "randn: %s", hipGetErrorString(e));
+  HIPCK(h, hipMemcpy(host_dst, h->ws[0].d_xt, rows * 2 * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int dhw_profile_enable(dhw_handle* h, int on) {
   if (!h) return DHW_ERR_ARG;

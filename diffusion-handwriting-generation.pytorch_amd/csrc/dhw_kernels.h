@@ -161,7 +161,7 @@ hipError_t launch_input_dense(int prec, const float* strokes, long rows, const f
 
 hipError_t launch_heads(const HeadsParams& p, hipStream_t st);
 // x_T ~ N(0,1) from Philox, same keying as the per-step draws (iter = -1)
-hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st);
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st, int iter = -1);
 // seed_ptr[0] = seed, seed_ptr[1] = first_sample (by-value kernel arguments: no host buffer lifetime)
 hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st);
 // one-time per-process kernel attribute setup (dynamic LDS > 64 KiB)

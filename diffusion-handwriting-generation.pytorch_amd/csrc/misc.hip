@@ -133,11 +133,12 @@ __global__ void set_seed_kernel(uint64_t* p, uint64_t seed, int64_t first) {
   p[1] = (uint64_t)first;
 }
 
-__global__ __launch_bounds__(256) void randn_init_kernel(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off) {
+// iter = -1: x_T; iter = k >= 0: the draw the k-th sampler step adds (the same call heads_finish makes)
+__global__ __launch_bounds__(256) void randn_init_kernel(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, int iter) {
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   float z0, z1;
-  normal2(seed_ptr[0], (int64_t)seed_ptr[1] + sample_off + row / L, (int)(row % L), -1, z0, z1);
+  normal2(seed_ptr[0], (int64_t)seed_ptr[1] + sample_off + row / L, (int)(row % L), iter, z0, z1);
   xt[row * 2] = z0;
   xt[row * 2 + 1] = z1;
 }
@@ -193,8 +194,8 @@ hipError_t launch_heads(const HeadsParams& p, hipStream_t st) {
   hipLaunchKernelGGL(heads_kernel, dim3(nblk(p.rows, 16)), dim3(256), 0, st, p);
   return hipGetLastError();
 }
-hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st) {
-  hipLaunchKernelGGL(randn_init_kernel, dim3(nblk(rows, 256)), dim3(256), 0, st, xt, rows, L, seed_ptr, sample_off);
+hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_ptr, int sample_off, hipStream_t st, int iter) {
+  hipLaunchKernelGGL(randn_init_kernel, dim3(nblk(rows, 256)), dim3(256), 0, st, xt, rows, L, seed_ptr, sample_off, iter);
   return hipGetLastError();
 }
 hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st) {

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .model import DiffusionModel
+from .model import DiffusionModel, check_token_ids
 from .tokenizer import Tokenizer, stroke_length
 
 
@@ -40,6 +40,7 @@ def sample(model: DiffusionModel, text: torch.Tensor, style_vector: torch.Tensor
         L = stroke_length(Lt)
     if L % 8:
         raise ValueError("L must be a multiple of 8")
+    check_token_ids(text)
     dev = model._device(text, style_vector)
     h = model._ensure_handle(dev, B, L, Lt, style_vector.shape[1])
     ret_dev = text.device

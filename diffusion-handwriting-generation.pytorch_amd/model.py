@@ -24,6 +24,16 @@ class _Node(nn.Module):
     """Name-space container so parameters keep the reference's dotted keys."""
 
 
+VOCAB = 73   # nn.Embedding(73, d_model), reference text_style.py:71
+
+
+def check_token_ids(text: torch.Tensor) -> None:
+    """The reference's ``nn.Embedding`` raises IndexError for an id outside [0, 73); the kernels would clamp it.  One
+    reduction + one host read per call, in front of the launch."""
+    if text.numel() and bool(((text < 0) | (text >= VOCAB)).any()):
+        raise IndexError(f"index out of range in self: token ids must lie in [0, {VOCAB})")
+
+
 def _torch_dtype_code(t: torch.Tensor) -> int:
     return {torch.float32: _lib.DHW_F32, torch.bfloat16: _lib.DHW_BF16, torch.float16: _lib.DHW_F16,
             torch.float64: _lib.DHW_F64}[t.dtype]
@@ -129,6 +139,7 @@ class DiffusionModel(nn.Module):
             raise ValueError("style_vector must be [B, S, 1280]")
         if sigma.numel() != B:
             raise ValueError("sigma must hold one value per sample ([B,1] or [B,1,1])")
+        check_token_ids(text)
         ret_dev = strokes.device
         dev = self._device(strokes, text, sigma, style_vector)
         h = self._ensure_handle(dev, B, L, text.shape[1], style_vector.shape[1])
@@ -156,6 +167,15 @@ class DiffusionModel(nn.Module):
         n = _lib.lib().dhw_debug_read(self._handle, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, shape)
         _lib.check(int(n), self._handle)
         return torch.from_numpy(buf[:n].reshape(shape[0], shape[1], shape[2]).copy())
+
+    def debug_randn(self, seed: int, first_sample: int, B: int, L: int, it: int = -1) -> torch.Tensor:
+        """The device generator's N(0,1) draws [B,L,2] for sampler iteration `it` (-1 = x_T): include/dhw_debug.h."""
+        import numpy as np
+        dev = self._device()
+        h = self._ensure_handle(dev, B, L, 1, self._cap["S"])
+        buf = np.empty((B, L, 2), np.float32)
+        _lib.check(_lib.lib().dhw_debug_randn(h, seed, first_sample, B, L, it, buf.ctypes.data_as(C.POINTER(C.c_float))), h)
+        return torch.from_numpy(buf)
 
     def profile(self, on: bool):
         _lib.check(_lib.lib().dhw_profile_enable(self._handle, int(on)), self._handle)

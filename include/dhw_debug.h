@@ -33,6 +33,11 @@ int dhw_set_streams(dhw_handle*, int n);
 /* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
 int dhw_set_graph(dhw_handle*, int on);
 
+/* The device noise generator on its own: the N(0,1) draws of `B` samples x `L` positions x 2 for sampler iteration
+ * `iter` (-1 = x_T, k >= 0 = the draw step k adds) under (seed, first_sample), copied to host_dst [B,L,2].
+ * Exactly the values dhw_sample(noise = NULL) consumes.  Synchronises the device. */
+int dhw_debug_randn(dhw_handle*, uint64_t seed, int64_t first_sample, int B, int L, int iter, float* host_dst);
+
 /* The logical workgroup id the fused kernels derive from blockIdx (csrc/dhw_common.h xcd_swizzle): a bijection of
  * [0, nwg) that gives each of the 8 XCDs a contiguous id range.  Host-side copy for tests; needs no device. */
 int dhw_debug_xcd_swizzle(int block_id, int nwg);

@@ -47,6 +47,12 @@ def test_config_maps_to_model_dims_and_strict_load(tmp_path):
     cfg = tmp_path / "config.yml"
     cfg.write_text("training_args:\n  att_layers_num: 2\n  channels: 128\n  dropout: 0.0\n")
     assert dhg_amd.read_config(cfg) == {"num_layers": 2, "c1": 128, "c2": 192, "c3": 256, "drop_rate": 0.0}
+    # an incomplete config fails here, as `cfg.training_args.<key>` does in the reference (checkpoint.py:280-286): no defaults
+    bad = tmp_path / "bad.yml"
+    for text in ("training_args:\n  att_layers_num: 2\n  channels: 128\n", "other: 1\n", ""):
+        bad.write_text(text)
+        with pytest.raises(KeyError):
+            dhg_amd.read_config(bad)
     ck = tmp_path / "model_final.pth"
     torch.save({"state_dict": _sd(2)}, ck)
     m = dhg_amd.load_model(cfg, ck)

@@ -22,7 +22,10 @@ from oracle import ref_cpu
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": dict(eps=2e-5, pen=2e-5, tap=5e-5), "bf16": dict(eps=2e-2, pen=5e-3, tap=1e-1)}
+# tap: absolute for fp32; for bf16 relative to the block output's own magnitude max|ref| (post-LayerNorm/FiLM outputs reach
+# |x| ~ 3.6, where ONE bf16 ulp is 0.0156): 1.5e-2 * max|ref| = ~4 bf16 ulps.  Measured (tools/measure_parity.py, r2):
+# 0.0033 .. 0.0097 * max|ref| over the 14 blocks.
+TOL = {"fp32": dict(eps=2e-5, pen=2e-5, tap=5e-5), "bf16": dict(eps=2e-2, pen=5e-3, tap_rel=1.5e-2)}
 _MODELS = {}
 
 
@@ -85,7 +88,16 @@ def test_every_block_matches_reference_taps(golden_dir, prec):
                  "att_layers.0", "att_layers.1", "dec3", "dec2", "dec1"):
         ref = g["tap_" + name]
         got = m.debug_read(name).numpy().reshape(ref.shape)
-        assert np.abs(got - ref).max() < TOL[prec]["tap"], name
+        tol = TOL[prec]["tap"] if prec == "fp32" else TOL[prec]["tap_rel"] * np.abs(ref).max()
+        assert np.abs(got - ref).max() < tol, (name, np.abs(got - ref).max(), tol)
+    if prec == "fp32":
+        # the skip convolutions (model.py:169-175): the fp32 path keeps `Upsample(x) + skip_conv(h)` as its own launch and
+        # exposes the sum; minus the up-sampled predecessor it is the reference's skip_conv module output
+        for skip, prev in (("skip_conv3", "att_layers.1"), ("skip_conv2", "dec3"), ("skip_conv1", "dec2")):
+            ref = g["tap_" + skip]
+            up = np.repeat(m.debug_read(prev).numpy(), 2, axis=1)
+            got = m.debug_read(skip + "+up").numpy().reshape(ref.shape) - up.reshape(ref.shape)
+            assert np.abs(got - ref).max() < TOL["fp32"]["tap"], skip
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -189,29 +201,13 @@ def test_full_size_batch_properties():
     # shard [40, 48) on its own handle-call, as a second GPU would run it
     shard = dhg_amd.sample(m, tx[40:48].contiguous(), sv[40:48].contiguous(), L=L, seed=7, first_sample=40).cpu()
     assert torch.equal(shard, full[40:48])
-    # noise statistics of the device generator: x_T ~ N(0,1) => after T steps still finite; check the draws directly
-    nz = torch.from_numpy(inp["noise"][:2]).cuda()
-    assert nz.shape[0] == 2
+    # (the device generator itself: tests/test_gpu_round2.py::test_device_noise_generator_moments_and_independence)
     # forward at full batch: batch independence of the denoiser
     sg = torch.full((B, 1), 0.7)
     e_full, p_full = fwd(m, inp, sg)
     sub = {k: v[10:12] for k, v in inp.items() if k != "noise"}
     e_sub, p_sub = fwd(m, sub, sg[10:12])
     assert np.array_equal(e_full[10:12], e_sub) and np.array_equal(p_full[10:12], p_sub)
-
-
-def test_device_noise_is_standard_normal():
-    m = get_model(2, "bf16")
-    B, L, Lt = 8, 488, 4
-    inp = spec.synthetic_inputs(B, L, Lt, seed=2)
-    # T=1, mode "new": x_0 = (x_T - k0*eps)/k1 + 0*z ; use the eps/x relation only for finiteness, and read x_T
-    # statistics through a zero-weight trick instead: with sigma-independent check we simply sample twice with
-    # different seeds and test the difference of the x_T-dominated outputs is non-degenerate.
-    a = dhg_amd.sample(m, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=1, seed=1).cpu()
-    b = dhg_amd.sample(m, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=1, seed=2).cpu()
-    d = (a[..., :2] - b[..., :2]).flatten()
-    assert torch.isfinite(d).all() and d.std() > 0.5
-    assert abs(d.mean().item()) < 0.1
 
 
 def test_error_behaviour_mirrors_the_reference():
@@ -305,7 +301,9 @@ def test_sampler_switches_do_not_change_the_samples(prec):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
         outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
     assert torch.equal(outs["default"], outs["no_plane"])
-    tol = 1e-4 if prec == "fp32" else 0.15   # fused vs unfused block kernels round intermediates at different points
+    # fused vs unfused block kernels round intermediates to bf16 at different points; |x| reaches ~9 after these 7 steps.
+    # Measured (r2): <= 0.03 for every pair
+    tol = 1e-4 if prec == "fp32" else 0.06
     assert (outs["default"] - outs["no_fused_heads"]).abs().max().item() < tol
     assert (outs["default"] - outs["no_fused_up"]).abs().max().item() < tol   # (bf16 only: fp32 keeps the separate GEMM)
     assert (outs["default"] - outs["no_chain"]).abs().max().item() < tol      # (bf16 only)

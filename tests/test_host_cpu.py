@@ -107,6 +107,20 @@ def test_fails_loudly_without_a_gpu():
         m(torch.zeros(1, 8, 2), torch.ones(1, 3, dtype=torch.long), torch.ones(1, 1), torch.zeros(1, 14, 1280))
 
 
+def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
+    """reference text_style.py:71 `nn.Embedding(73, ...)` raises IndexError; the kernels would clamp silently"""
+    from dhg_amd.model import check_token_ids
+    check_token_ids(torch.tensor([[0, 1, 72]]))
+    for bad in ([[73]], [[-1, 3]], [[5, 1000]]):
+        with pytest.raises(IndexError):
+            check_token_ids(torch.tensor(bad))
+    m = dhg_amd.DiffusionModel(2)
+    with pytest.raises(IndexError):    # checked before the device is touched
+        m(torch.zeros(1, 8, 2), torch.tensor([[73]]), torch.ones(1, 1), torch.zeros(1, 14, 1280))
+    with pytest.raises(IndexError):
+        dhg_amd.sample(m, torch.tensor([[1, 99]]), torch.zeros(1, 14, 1280), L=8)
+
+
 def test_create_rejects_bad_dims():
     l = _lib.lib()
     h = C.c_void_p()
