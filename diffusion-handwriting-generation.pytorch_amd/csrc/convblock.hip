@@ -22,9 +22,14 @@
 
 namespace {
 
+// diagnostic builds only (-DDHW_ABL=n, tools/build_tools.sh): bit3 = SiLU -> identity, bit4 = no output / pool copy-out,
+// bit5 = x tile not loaded (zeros), bit6 = workgroup barriers removed (results are wrong; only the timing is read)
+#define CB_SILU(x) ((DHW_ABL & 8) ? (x) : silu_t<T>(x))
+#define CB_BARRIER() do { if constexpr (!(DHW_ABL & 64)) lds_barrier(); } while (0)
+
 #define STAMP(slot)                                                                                   \
   do {                                                                                                \
-    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+    if (p.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) p.stamps[(threadIdx.x >> 6) * 16 + slot] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
 // Row stride of the h2 / output staging tile: the conflict-free operand padding, except for the 126-row tiles, where the
@@ -50,10 +55,16 @@ struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles,
 // UPC = 0, or the block's input width Cin when the input itself is produced here (decoder blocks):
 // x = Upsample(low) + skip_conv(h) (model.py:169-175), one more 3-tap GEMM stage in front of the block.
 // CH = 1: the workgroup continues with enc_a of the EncoderLayer that follows the block (nx.a) on its output tile.
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
+// CIN = the block's input width when it is compiled in (0 = run-time p.Cin): the weight rings of the stages that contract
+// over Cin then request exactly their fragments (gemm_core.h, fill_s / run_s) instead of clamped look-ahead re-loads.
+template <int UPC> constexpr int up_skip_width() { return UPC == 384 ? 256 : UPC == 256 ? 192 : UPC == 192 ? 128 : 0; }   // model.py:169-175
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
+  constexpr bool SK = CIN != 0;          // static contraction lengths
+  constexpr int KT1 = 3 * CIN / 32;      // conv1 / conv_skip k-chunks when SK
+  static_assert(UPC == 0 || CIN == 0 || CIN == UPC, "a fused input stage produces the block's own input width");
   constexpr int BMO = BM - 2;            // output rows per workgroup
   constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
   constexpr int C1 = CO / 2;             // conv1 output channels
@@ -87,7 +98,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int b = bid / tiles;
   const int m0 = (bid % tiles) * BMO;
-  const int Cin = p.Cin;
+  const int Cin = SK ? CIN : p.Cin;
 
   const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = h2_stride<T, BM>(CO);
   char* XS = smem;                       // SiLU(x)   [RX][Cin]
@@ -104,9 +115,21 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
 
+  if constexpr (OCC == 2) {
+    // co-resident workgroups that run the same program in lockstep reach their MFMA phases, VALU epilogues and barriers
+    // together; starting the later-dispatched half of the grid a fraction of a stage late lets one's epilogue overlap
+    // the other's matrix work (MI355X_MICROARCH.md, Two waves per SIMD, item 9)
+    if (p.stagger && blockIdx.x >= gridDim.x / 2)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   STAMP(0);
   WRing<T, NT1, RING> ring1;
   Epi<NT1> ep1;
+  auto fill1 = [&]() {
+    const T* w = reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8;
+    if constexpr (SK) ring1.template fill_s<KT1>(w);
+    else ring1.fill(w, KCin * 3);
+  };
 
   // ---- stage 0: x tile -> LDS (raw + SiLU), zero outside the sample ('same' padding)
   if constexpr (UPC != 0) {
@@ -118,7 +141,8 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     static_assert(NTU * WNU == TU && NW == 8, "unsupported input width");
     const bool actu = wave < WNU;
     const int ntu0 = (actu ? wave : 0) * NTU, nu = ntu0 * 16 + 4 * g;
-    const int Ch = p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);
+    constexpr int UCH = up_skip_width<UPC>();
+    const int Ch = SK ? UCH : p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);
     char* HS = H1;
     WRing<T, NTU, (NTU * MTU >= 24 ? 12 : RING)> ringu;
     Epi<NTU> epu;
@@ -136,17 +160,21 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
           [&](int id) { const int r = id / cpx, cc = id - r * cpx; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); });
     }
     if (actu) {   // (requested behind the staging loads: see below)
-      ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
+      if constexpr (SK) ringu.template fill_s<3 * UCH / 32>(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8);
+      else ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
       epu.load(p.up_b, nullptr, nullptr, nu);
     }
-    lds_barrier();
+    CB_BARRIER();
     STAMP(10);
     f32x4 acc[NTU][MTU];
     acc_zero(acc);
-    if (actu) ringu.template run<MTU>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
+    if (actu) {
+      if constexpr (SK) ringu.template run_s<MTU, 3 * UCH / 32>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
+      else ringu.template run<MTU>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
+    }
     STAMP(11);
     if (act1) {
-      ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);   // flies during the epilogue
+      fill1();   // flies during the epilogue
       ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
     }
     if (actu) {
@@ -162,7 +190,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               v[k] = (lrow >= 0 && lrow < p.L) ? to_f(from_f<T>(v[k])) : 0.f;   // the block's own 'same' padding
-              sv[k] = silu_t<T>(v[k]);
+              sv[k] = CB_SILU(v[k]);
             }
             store4(xp, v);
             store4(reinterpret_cast<T*>(XS + r * SX) + nu + 16 * i, sv);
@@ -182,7 +210,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           v[k] = to_f(from_f<T>(p.in_w[(c + k) * 2] * s0 + p.in_w[(c + k) * 2 + 1] * s1 + p.in_b[c + k]));
-          sv[k] = silu_t<T>(v[k]);
+          sv[k] = CB_SILU(v[k]);
         }
       }
       store4(reinterpret_cast<T*>(XR + r * SX) + c, v);
@@ -203,7 +231,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         const int lrow = m0 - 2 + r;
         v[u] = make_uint4(0, 0, 0, 0);
         dst[u] = id < total ? r * SX + cc * 16 : -1;
-        if (id < total && lrow >= 0 && lrow < p.L)
+        if (id < total && lrow >= 0 && lrow < p.L && !(DHW_ABL & 32))
           v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Cin) * ES + (size_t)cc * 16);
       }
 #pragma unroll
@@ -212,7 +240,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         *reinterpret_cast<uint4*>(XR + dst[u]) = v[u];
         T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
-        for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_t<T>(to_f(e[i])));
+        for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(CB_SILU(to_f(e[i])));
         *reinterpret_cast<uint4*>(XS + dst[u]) = v[u];
       }
     }
@@ -220,10 +248,11 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   // the first stage's weights are requested BEHIND the staging loads (a wave's loads complete in order and the L1 miss
   // queue is shared: a 24 KB-per-wave prefetch in front of them delays the tile everything waits for)
   if (UPC == 0 && act1) {
-    ring1.fill(reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8, KCin * 3);
+    fill1();
     ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
   }
-  lds_barrier();   // x tiles complete (and the staged skip rows, which overlay h1, consumed)
+  STAMP(15);
+  CB_BARRIER();   // x tiles complete (and the staged skip rows, which overlay h1, consumed)
   STAMP(1);
 
   WRing<T, NT2, RING> ring2;
@@ -233,10 +262,13 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   {
     f32x4 acc[NT1][MT1];
     acc_zero(acc);
-    if (act1) ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+    if (act1) {
+      if constexpr (SK) ring1.template run_s<MT1, KT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+      else ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
+    }
     STAMP(2);
     if (act2) {
-      ring2.fill(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8, (C1 / 32) * 3);
+      ring2.template fill_s<(C1 / 32) * 3>(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8);
       ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
     }
     if (act1) {
@@ -248,7 +280,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
           const int srow = m0 - 1 + r;
           f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? silu_t<T>(v[k]) : 0.f;   // conv2 pads h1 with zeros
+          for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? CB_SILU(v[k]) : 0.f;   // conv2 pads h1 with zeros
           store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
         }
     }
@@ -256,46 +288,50 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
       *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   }
-  lds_barrier();
+  STAMP(13);
+  CB_BARRIER();
   STAMP(3);
 
   // ---- stage 2: h2 = SiLU(FiLM2(conv2(h1))) for sample rows [m0, m0+BM) (the last 2 are discarded)
   if (act2) {
     f32x4 acc[NT2][MT2];
     acc_zero(acc);
-    ring2.template run<MT2>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
+    ring2.template run_s<MT2, (C1 / 32) * 3>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
     STAMP(4);
-    ring2.fill(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * (CO / 32) * 64 + lane) * 8, CO / 32);
+    ring2.template fill_s<CO / 32>(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * (CO / 32) * 64 + lane) * 8);
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j) {
         f32x4 v = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
+        for (int k = 0; k < 4; ++k) v[k] = CB_SILU(v[k]);
         store4(reinterpret_cast<T*>(H2 + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, v);
       }
     ep2.load(p.b_fc, gam + p.f3, bet + p.f3, n2);
   }
-  lds_barrier();
+  STAMP(14);
+  CB_BARRIER();
   STAMP(5);
 
   // ---- stage 3: out = FiLM3(fc(h2)) + conv_skip(x)
   f32x4 acc[NT2][MT2];
   acc_zero(acc);
   if (act2) {
-    ring2.template run<MT2>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
+    ring2.template run_s<MT2, CO / 32>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
     STAMP(6);
-    ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
+    if constexpr (SK) ring2.template fill_s<KT1>(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8);
+    else ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
     ep2.load(p.b_skip, nullptr, nullptr, n2);
-    ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+    if constexpr (SK) ring2.template run_s<MT2, KT1>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
+    else ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);
   }
   STAMP(7);
-  lds_barrier();   // every wave is done with the operand tiles: reuse LDS for the output tile
+  CB_BARRIER();   // every wave is done with the operand tiles: reuse LDS for the output tile
   STAMP(8);
 
   const int rows_valid = min(BMO, p.L - m0);
@@ -308,7 +344,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         for (int j = 0; j < MT2; ++j)
           store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
     }
-    lds_barrier();
+    CB_BARRIER();
     if (p.out)
       tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.fuse_heads) {
@@ -342,9 +378,10 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
         for (int j = 0; j < MT2; ++j)
           store4(reinterpret_cast<T*>(smem + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
     }
-    lds_barrier();
+    CB_BARRIER();
+    if constexpr (!(DHW_ABL & 16))
     tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
-    if (p.pool)   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
+    if (p.pool && !(DHW_ABL & 16))   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
       tile_copy_out_pool<T>(smem, SH2, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * CO, CO, rows_valid, CO, tid, NTHR);
     if constexpr (CH == 1) {
       // the output tile (rows [m0, m0 + rows_valid), row stride SH2 = tile_stride(CO)) is the next layer's x tile
@@ -371,47 +408,45 @@ size_t lds_bytes(int Cin, int up_cin = 0) {
   return std::max(ops, std::max(outf, up));
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
   size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
   if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>());
   if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32)) || (CH != 0) != (nx != nullptr)) return hipErrorInvalidValue;
+  if (CIN && (p.Cin != CIN || (UPC && p.up_cin != up_skip_width<UPC>()))) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+
+// The reference's encoder blocks (model.py:85-89): Cout 128 <- 128, 192 <- 128, 256 <- 192; these input widths are compiled in.
+constexpr int enc_cin(int CO) { return CO == 256 ? 192 : 128; }
 
 }  // namespace
 
 hipError_t convblock_init() {
   hipError_t e;
-  if ((e = attr<bf16_t, 64, 128, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 128, 128, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 128, 8, 2>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192, 8, 2>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 128, 4, 2>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192, 4, 2>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 256, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 32, 256, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 128, 8, 1, 192>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 128, 128, 8, 1, 192>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192, 8, 1, 256>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 256, 8, 1, 384>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 48, 256, 8, 1, 384>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 48, 256, 8>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 192, 8, 1, 0, 1>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 48, 256, 8, 1, 0, 1>()) != hipSuccess) return e;
-  if ((e = attr<bf16_t, 64, 256, 8, 1, 0, 1>()) != hipSuccess) return e;
-  if ((e = attr<float, 32, 128, 4>()) != hipSuccess) return e;
-  if ((e = attr<float, 32, 192, 4>()) != hipSuccess) return e;
-  return attr<float, 32, 256, 4>();
+#define A(...) if ((e = attr<__VA_ARGS__>()) != hipSuccess) return e
+  // run-time input width (decoder blocks without the fused input stage, experiments)
+  A(bf16_t, 64, 128, 8); A(bf16_t, 128, 128, 8); A(bf16_t, 64, 128, 8, 2); A(bf16_t, 64, 192, 8, 2); A(bf16_t, 64, 192, 8);
+  A(bf16_t, 64, 256, 8); A(bf16_t, 32, 256, 8); A(bf16_t, 48, 256, 8);
+  // encoder blocks, input width compiled in
+  A(bf16_t, 64, 128, 8, 1, 0, 0, 128); A(bf16_t, 128, 128, 8, 1, 0, 0, 128); A(bf16_t, 64, 192, 8, 1, 0, 0, 128);
+  A(bf16_t, 64, 256, 8, 1, 0, 0, 192); A(bf16_t, 48, 256, 8, 1, 0, 0, 192);
+  // decoder blocks with the fused Upsample + skip_conv input stage
+  A(bf16_t, 64, 128, 8, 1, 192, 0, 192); A(bf16_t, 128, 128, 8, 1, 192, 0, 192); A(bf16_t, 64, 192, 8, 1, 256, 0, 256);
+  A(bf16_t, 64, 256, 8, 1, 384, 0, 384); A(bf16_t, 48, 256, 8, 1, 384, 0, 384);
+  // encoder blocks that continue into the next EncoderLayer's first half
+  A(bf16_t, 64, 192, 8, 1, 0, 1, 128); A(bf16_t, 48, 256, 8, 1, 0, 1, 192); A(bf16_t, 64, 256, 8, 1, 0, 1, 192);
+  A(float, 32, 128, 4); A(float, 32, 192, 4); A(float, 32, 256, 4);
+#undef A
+  return hipSuccess;
 }
 
 // 46-row tiles for the widest blocks (L/4 level) when the 62-row tiling leaves CUs idle and the finer one still fits one round
@@ -421,38 +456,41 @@ static bool use_bm48(const ConvBlockParams& p) {
   return t64 < 256 && t48 <= 256 && t48 > t64;
 }
 
-hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st) {
+hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t st) {
+  ConvBlockParams p = p_in;
+  if (const char* e = getenv("DHW_CONV_STAGGER")) p.stagger = atoi(e);
   if (p.Cin % 32 || (p.L & 1) || (p.pool && p.out_f32) || (p.fuse_heads && !p.out_f32) || (!p.out && !p.fuse_heads)) return hipErrorInvalidValue;
+  static const bool rt = getenv("DHW_CONV_RT") && atoi(getenv("DHW_CONV_RT"));   // A/B: force the run-time-width variants
   if (p.up_h) {   // decoder block with the fused Upsample + skip_conv input stage (bf16 only)
     if (prec != PREC_BF16 || p.strokes || !p.up_w || !p.up_b || !p.up_low) return hipErrorInvalidValue;
-    if (p.Cout == 128 && p.Cin == 192) {
+    if (p.Cout == 128 && p.Cin == 192 && p.up_cin == 128) {
       const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
-      return big ? launch_t<bf16_t, 128, 128, 8, 1, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192>(p, st);
+      return big ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192, 0, 192>(p, st);
     }
-    if (p.Cout == 192 && p.Cin == 256) return launch_t<bf16_t, 64, 192, 8, 1, 256>(p, st);
-    if (p.Cout == 256 && p.Cin == 384) return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 384>(p, st) : launch_t<bf16_t, 64, 256, 8, 1, 384>(p, st);
+    if (p.Cout == 192 && p.Cin == 256 && p.up_cin == 192) return launch_t<bf16_t, 64, 192, 8, 1, 256, 0, 256>(p, st);
+    if (p.Cout == 256 && p.Cin == 384 && p.up_cin == 256)
+      return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 384, 0, 384>(p, st) : launch_t<bf16_t, 64, 256, 8, 1, 384, 0, 384>(p, st);
     return hipErrorInvalidValue;
   }
   if (prec == PREC_BF16) {
+    const bool sk = !rt && p.Cin == enc_cin(p.Cout);   // an encoder block: static contraction lengths
     switch (p.Cout) {
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
         const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
-        if (getenv("DHW_CONV_NW") && atoi(getenv("DHW_CONV_NW")) == 4 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
-          return launch_t<bf16_t, 64, 128, 4, 2>(p, st);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 128, 8, 2>(p, st);
+        if (sk) return big ? launch_t<bf16_t, 128, 128, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 0, 0, 128>(p, st);
         return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
       }
       case 192:
-        if (getenv("DHW_CONV_NW") && atoi(getenv("DHW_CONV_NW")) == 4 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
-          return launch_t<bf16_t, 64, 192, 4, 2>(p, st);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 192, 8, 2>(p, st);
-        return launch_t<bf16_t, 64, 192, 8>(p, st);
+        return sk ? launch_t<bf16_t, 64, 192, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
-        if (use_bm48(p)) return launch_t<bf16_t, 48, 256, 8>(p, st);
-        return (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) ? launch_t<bf16_t, 32, 256, 8>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);
+        if (use_bm48(p)) return sk ? launch_t<bf16_t, 48, 256, 8, 1, 0, 0, 192>(p, st) : launch_t<bf16_t, 48, 256, 8>(p, st);
+        if (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) return launch_t<bf16_t, 32, 256, 8>(p, st);
+        return sk ? launch_t<bf16_t, 64, 256, 8, 1, 0, 0, 192>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);
     }
   } else {
     switch (p.Cout) {
@@ -470,11 +508,11 @@ bool convblock_chain_supported(int prec, const ConvBlockParams& p, const EncChai
   if (prec != PREC_BF16 || chain.mode != 1 || chain.a.x || p.up_h || p.strokes || p.out_f32 || p.fuse_heads) return false;
   if (chain.a.d != p.Cout || chain.a.Lk != p.L || chain.a.B != p.B || (p.L & 1)) return false;
   if (getenv("DHW_CONV_BM") || getenv("DHW_CONV_OCC")) return false;
-  return (p.Cout == 192 || p.Cout == 256) && enclayer_supported(prec, chain.a.d, chain.a.heads);
+  return (p.Cout == 192 || p.Cout == 256) && p.Cin == enc_cin(p.Cout) && enclayer_supported(prec, chain.a.d, chain.a.heads);
 }
 
 hipError_t launch_convblock_chain(int prec, const ConvBlockParams& p, const EncChain& chain, hipStream_t st) {
   if (!convblock_chain_supported(prec, p, chain) || p.Cin % 32 || (!p.out)) return hipErrorInvalidValue;
-  if (p.Cout == 192) return launch_t<bf16_t, 64, 192, 8, 1, 0, 1>(p, st, &chain);
-  return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 0, 1>(p, st, &chain) : launch_t<bf16_t, 64, 256, 8, 1, 0, 1>(p, st, &chain);
+  if (p.Cout == 192) return launch_t<bf16_t, 64, 192, 8, 1, 0, 1, 128>(p, st, &chain);
+  return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 0, 1, 192>(p, st, &chain) : launch_t<bf16_t, 64, 256, 8, 1, 0, 1, 192>(p, st, &chain);
 }

@@ -89,6 +89,7 @@ struct ConvBlockParams {
   int fuse_heads;                     // dec1 in the sampling loop: evaluate the eps/pen heads + scheduler step from the fp32
   HeadsParams hp;                     //   output tile in LDS (hp.x/rows/C unused); `out` may then be null (no activation write)
   unsigned long long* stamps;         // diagnostics only: per-stage s_memrealtime of workgroup 0, or null
+  int stagger;                        // two-workgroups-per-CU variants: the second half of the grid starts this many x 0.5 us late
 };
 hipError_t launch_convblock(int prec, const ConvBlockParams& p, hipStream_t st);
 hipError_t convblock_init();

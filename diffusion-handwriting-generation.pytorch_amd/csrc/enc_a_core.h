@@ -112,7 +112,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   // the q1 weights are requested BEHIND the staging loads: a wave's loads complete in order and the L1 miss queue is
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_q1) + wlane, KC);
+    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane);
     ep.load(p.b_q1, nullptr, nullptr, n0);
   }
   lds_barrier();
@@ -127,7 +127,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
 #pragma unroll
       for (int j = 0; j < MT; ++j)
         pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + row0 + j * 16 + l15) * DM + n0 + 16 * i));
-    ring.template run<MT>(acc, xop, S, KC);
+    ring.template run_s<MT, KC>(acc, xop, S, KC);
     ENC_STAMP(8);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -189,7 +189,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     }
   }
   if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_d1) + wlane, KC);   // in flight across the barrier
+    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);   // in flight across the barrier
     ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
   }
   lds_barrier();
@@ -199,9 +199,9 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     f32x4 acc[NT][MT];
     acc_zero(acc);
     if (act) {
-      ring.template run<MT>(acc, qop, S, KC);
+      ring.template run_s<MT, KC>(acc, qop, S, KC);
       ENC_STAMP(10);
-      ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + wlane, KC);   // q2 chunk: flies during the LayerNorm epilogue
+      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -243,9 +243,9 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
           for (int j = 0; j < MT; ++j)
             pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
       }
-      ring.template run<MT>(acc, xop + opaque, S, KC);
+      ring.template run_s<MT, KC>(acc, xop + opaque, S, KC);
       ENC_STAMP(12 + chunk);
-      if (chunk < 2) ring.fill(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane, KC);
+      if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane);
     }
     if (chunk < 2 && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (act) {
-    ring.fill(reinterpret_cast<const T*>(p.w_d2) + wlane, KC);   // in flight across the barrier
+    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
     ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
   }
   lds_barrier();
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           res[i][j] = r < p.Lk ? load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i))
                                : (f32x4){0, 0, 0, 0};
         }
-      ring.template run<MT>(acc, op1, S, KC);
-      ring.fill(reinterpret_cast<const T*>(p.w_f1) + wlane, KC);   // FFN half 0: flies during the LayerNorm epilogue
+      ring.template run_s<MT, KC>(acc, op1, S, KC);
+      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -201,9 +201,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       f32x4 acc[NT][MT];
       acc_zero(acc);
       ep.load(p.b_f1 + hh * DM, nullptr, nullptr, n0);
-      ring.template run<MT>(acc, op1, S, KC);
+      ring.template run_s<MT, KC>(acc, op1, S, KC);
       // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
-      ring.fill(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, KC, 2 * KC);
+      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     lds_barrier();
     STAMP(20 + 2 * hh);
     if (act) {
-      ring.template run<MT>(acc2, op3, S, KC);
-      if (hh == 0) ring.fill(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane, KC);   // FFN half 1
+      ring.template run_s<MT, KC>(acc2, op3, S, KC);
+      if (hh == 0) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // FFN half 1
     }
     if (hh == 0) lds_barrier();   // R3 is rewritten by the next half (after the last one the LayerNorm barrier below does)
     STAMP(21 + 2 * hh);
@@ -276,14 +276,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     WRing<T, NTN> rd;
     EpiParams<NTN> epd;
     const int nt0 = wave * NTN, nn0 = nt0 * 16 + 4 * g;
-    rd.fill(reinterpret_cast<const T*>(nx.w_dense) + ((size_t)nt0 * KC * 64 + lane) * 8, KC);
+    rd.template fill_s<KC>(reinterpret_cast<const T*>(nx.w_dense) + ((size_t)nt0 * KC * 64 + lane) * 8);
     epd.load(nx.b_dense, nullptr, nullptr, nn0);
     lds_barrier();   // pooled tile complete; every read of the out tile (copy-out, pooling) is done
     char* XN = R2;   // x tile of the chained layer, then its q1 tile: together BM * SN <= 2 * BM * S bytes over R2..R3
     {
       f32x4 acc[NTN][MTN];
       acc_zero(acc);
-      rd.template run<MTN>(acc, R1 + l15 * S + g * 8 * ES, S, KC);
+      rd.template run_s<MTN, KC>(acc, R1 + l15 * S + g * 8 * ES, S, KC);
 #pragma unroll
       for (int i = 0; i < NTN; ++i)
 #pragma unroll

@@ -20,6 +20,9 @@ DHW_DEV void keep_alive(const Frag<float>& f) { asm volatile("" ::"v"(f.lo), "v"
 // ISSUES the first D k-chunks' loads, so a caller can start the NEXT stage's weight stream before it runs the
 // current stage's epilogue / barrier (the loads fly during the epilogue); run() consumes the ring.
 // ABL (diagnostic builds only, tools/bench_stage.cpp): bit0 = no MFMA, bit1 = no weight re-loads, bit2 = no LDS reads
+#ifndef DHW_ABL
+#define DHW_ABL 0   // diagnostic builds only (-DDHW_ABL=n): default ablation mask of every main loop
+#endif
 template <typename T, int NT, int RING = (sizeof(T) == 2 ? 24 : 12)>
 struct WRing {
   static constexpr int D0 = RING / NT;
@@ -46,7 +49,7 @@ struct WRing {
   //   abase : LDS address of (this wave's first row + lane&15, element (lane>>4)*8) incl. any row offset;
   //   stride: LDS row stride in bytes (tap t reads t rows further);  KC: k-chunks per tap (KT = KC * taps).
   // The body is branch-free and statically indexed so hipcc emits counted s_waitcnt vmcnt((D-1)*NT).
-  template <int MT, int ABL = 0>
+  template <int MT, int ABL = DHW_ABL>
   DHW_DEV void run(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
     constexpr int ES = sizeof(T);
     int aoff = 0, kc = 0;
@@ -82,6 +85,63 @@ struct WRing {
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (kt + d < KT) step(d, KT - 1);
+  }
+
+  // ---- compile-time KT (the hot variants): exactly the stage's KT x NT fragments are requested, each once.
+  // A load whose result is never consumed is not "harmless": its destination registers cannot be reused until it has
+  // landed, so hipcc drains the whole queue (s_waitcnt vmcnt(0): one L2 round trip under load) in front of the next
+  // stage's prefetch and the epilogue.  The run-time-KT form above clamps the look-ahead index instead (D redundant
+  // re-loads of the last fragment per stage) and pays that drain after every main loop: 1.3-1.7 us per stage in the
+  // ConvBlock (per-wave stamps, profiles/r02_convblock_wave_stamps.log).  With KT known, every step statically knows
+  // whether chunk s + D exists, so the whole loop stays branch-free with counted waits.
+  DHW_DEV void load_chunk(int d, int k) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) q[d][i] = frag_load(base + ((size_t)i * KTS + k) * 512);
+  }
+  template <int KT_>
+  DHW_DEV void fill_s(const T* __restrict__ wbase, int kts = 0) {
+    base = wbase;
+    KT = KT_;
+    KTS = kts ? kts : KT_;
+#pragma unroll
+    for (int d = 0; d < (D < KT_ ? D : KT_); ++d) load_chunk(d, d);
+  }
+  template <int MT, int KT_, int ABL = DHW_ABL>
+  DHW_DEV void run_s(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
+    constexpr int ES = sizeof(T);
+    constexpr int NR = KT_ > D ? KT_ - D : 0;   // steps that re-load their slot (chunk s + D exists)
+    constexpr int G = NR / D;                   // of which whole groups of D run as a loop
+    int aoff = 0, kc = 0;
+    const int tap_step = stride - (KC - 1) * 32 * ES;
+    auto step = [&](int d, bool reload, int knext) {
+      Frag<T> a[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        if constexpr (ABL & 4) a[j] = frag_zero<T>();
+        else a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          if constexpr (ABL & 1) { keep_alive(q[d][i]); keep_alive(a[j]); }
+          else mma32(acc[i][j], q[d][i], a[j]);
+        }
+      if constexpr (!(ABL & 2)) {
+        if (reload) load_chunk(d, knext);   // (compile-time constant after unrolling)
+      }
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+    int kt = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g, kt += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) step(d, true, kt + d + D);
+    }
+#pragma unroll
+    for (int j = 0; j < KT_ - G * D; ++j) step(j % D, G * D + j + D < KT_, G * D + j + D);
   }
 };
 

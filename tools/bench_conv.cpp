@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
                       {"dec3+up", 122, 384, 256, 256}, {"dec2+up", 244, 256, 192, 192}, {"dec1+up", 488, 192, 128, 128}};
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  unsigned long long* stamps; CK(hipMalloc(&stamps, 64 * 8));
+  unsigned long long* stamps; CK(hipMalloc(&stamps, 256 * 8));
   for (const Cfg& c : cfgs) {
     ConvBlockParams p{};
     const size_t rows = (size_t)B * c.L + 128;
@@ -30,14 +30,18 @@ int main(int argc, char** argv) {
     p.film = (float*)dev_rand(1 << 20, true); p.film_bs = 0; p.film_tot = 9280; p.f1 = 0; p.f2 = 256; p.f3 = 512;
     if (c.up) { p.up_h = dev_rand(rows * c.up * 2); p.up_cin = c.up; p.up_w = dev_rand((size_t)6 * c.up * c.cin); p.up_b = p.b_c1; p.up_low = p.x; }
     p.out = dev_rand(rows * c.cout * 2); p.out_f32 = 0; p.pool = nullptr; p.stamps = stamps;
-    CK(hipMemset(stamps, 0, 64 * 8));
+    CK(hipMemset(stamps, 0, 256 * 8));
     for (int i = 0; i < 3; ++i) CK(launch_convblock(PREC_BF16, p, st));
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) CK(launch_convblock(PREC_BF16, p, st));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long h[64]; CK(hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long hw[256]; CK(hipMemcpy(hw, stamps, sizeof hw, hipMemcpyDeviceToHost));
+    unsigned long long* h = hw;   // wave 0
+    if (getenv("STAMP_WAVES")) {   // every wave's stamps relative to wave 0's first
+      for (int w = 0; w < 8; ++w) { printf("    wave %d:", w); for (int sl = 0; sl < 16; ++sl) printf(" %6.2f", hw[w * 16 + sl] ? ((double)hw[w * 16 + sl] - (double)hw[0]) / 100.0 : -1.0); printf("\n"); }
+    }
     printf("%s L=%d %d->%d: %.2f us/launch (%d WGs); WG0 stamps [us]: stage0 %.2f | s1 run %.2f epi+bar %.2f | s2 run %.2f epi+bar %.2f | fc %.2f skip %.2f | bar %.2f out %.2f\n",
            c.n, c.L, c.cin, c.cout, ms * 1e3 / reps, B * ((c.L + 61) / 62),
            (h[1]-h[0])/100.0, (h[2]-h[1])/100.0, (h[3]-h[2])/100.0, (h[4]-h[3])/100.0, (h[5]-h[4])/100.0, (h[6]-h[5])/100.0, (h[7]-h[6])/100.0, (h[8]-h[7])/100.0, (h[9]-h[8])/100.0);

@@ -11,3 +11,10 @@ $H -c tools/bench_enc.cpp -o tools/bin/bench_enc.o && hipcc --offload-arch=gfx95
 $H -c tools/bench_text.cpp -o tools/bin/bench_text.o && hipcc --offload-arch=gfx950 tools/bin/bench_text.o $P/gemm.o -o tools/bin/bench_text
 for t in bench_l2 bench_copy bench_handoff bench_lat; do $H tools/$t.cpp -o tools/bin/$t; done
 echo "built: $(ls tools/bin | grep -v '\.o$' | tr '\n' ' ')"
+# ablation builds of the ConvBlock bench (diagnostics; DHW_ABL bit mask, see csrc/convblock.hip): tools/bin/bench_conv_abl<N>
+if [ -n "$DHW_BUILD_ABL" ]; then
+  for abl in $DHW_BUILD_ABL; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_ABL=$abl -x hip -c "diffusion-handwriting-generation.pytorch_amd/csrc/convblock.hip" -o /tmp/convblock_abl$abl.o &&
+      hipcc --offload-arch=gfx950 tools/bin/bench_conv.o /tmp/convblock_abl$abl.o $P/enclayer.o -o tools/bin/bench_conv_abl$abl
+  done
+fi
