@@ -1462,7 +1462,9 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
 
   const bool graph = h->use_graph && !h->prof;
   if (!graph) {
-    rc = sample_enqueue_all(h, false, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
+    // eager launches: sub-batches still fork onto the side streams (concurrent kernels of different sub-batches);
+    // profiling keeps one stream so the per-launch events bracket one kernel each
+    rc = sample_enqueue_all(h, !h->prof, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
     const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain};
     auto it = h->graphs.find(key);

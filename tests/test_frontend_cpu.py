@@ -85,3 +85,18 @@ def test_strokes_to_polylines_follows_the_reference_plot_loop():
     # pen-up at rows 2 and 5: the stretch before row 2, then rows 2..4; the tail after the last lift is not drawn (vis.py:19-31)
     assert [l.tolist() for l in lines] == [[[1, 0], [2, 0]], [[2, 1], [3, 1], [4, 2]]]
     assert dhg_amd.strokes_to_polylines(np.zeros((4, 3), np.float32)) == []
+
+
+def test_polylines_match_the_reference_show_strokes(golden_dir):
+    """tests/golden/vis.npz: the (x, y) arrays of every `plt.plot` call the reference's show_strokes (utils/vis.py:5-36)
+    makes for a seeded stroke array, recorded by oracle/make_golden_r2.py — incl. a pen-up on row 0 (empty first
+    polyline) and a pen value of exactly 0.5 (numpy rounds half to even: no split)."""
+    g = np.load(os.path.join(golden_dir, "vis.npz"))
+    lines = dhg_amd.strokes_to_polylines(g["strokes"])
+    assert len(lines) == int(g["n_lines"]) and [len(l) for l in lines] == g["lens"].tolist()
+    xs = np.concatenate([l[:, 0] for l in lines])
+    ys = np.concatenate([l[:, 1] for l in lines])
+    assert np.array_equal(xs, g["xs"]) and np.array_equal(ys, g["ys"])
+    pos = np.cumsum(g["strokes"][:, :2], axis=0).T
+    w, h = np.max(pos, axis=-1) - np.min(pos, axis=-1)
+    assert np.allclose([w / h, 1.0], g["figsize"], rtol=1e-6)       # the figure size show_strokes asks for (scale = 1)
