@@ -55,6 +55,16 @@ SIGNATURES = {
     "dhw_set_graph": (C.c_int, [_P, C.c_int]),
     "dhw_debug_xcd_swizzle": (C.c_int, [C.c_int, C.c_int]),
     "dhw_set_streams": (C.c_int, [_P, C.c_int]),
+    # include/dhw_style.h
+    "dhw_style_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
+    "dhw_style_load": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "dhw_style_finalize": (C.c_int, [_P]),
+    "dhw_style_num_keys": (C.c_int, [_P]),
+    "dhw_style_key_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "dhw_style_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "dhw_style_debug_features": (C.c_int64, [_P, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
+    "dhw_style_last_error": (C.c_char_p, [_P]),
+    "dhw_style_destroy": (None, [_P]),
     "dhw_debug_randn": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 
@@ -80,9 +90,9 @@ def lib():
     return l
 
 
-def check(code: int, handle=None):
+def check(code: int, handle=None, style: bool = False):
     if code < 0:
-        msg = lib().dhw_last_error(handle)
+        msg = (lib().dhw_style_last_error if style else lib().dhw_last_error)(handle)
         raise DhwError(code, msg.decode() if msg else "?")
     return code
 

@@ -36,6 +36,7 @@ struct GemmParams {
   int res2_half;
   int ln;                // LayerNorm over the N channels (eps 1e-6, no affine); needs BN == N
   int silu_out;
+  int relu6_out;         // clamp to [0, 6] (MobileNetV2 pointwise convolutions of the StyleExtractor, style.hip)
   void* out;             // [B*L, n_store] element type, or fp32 when out_f32
   int out_f32;
   void* pool;            // optional second output: AvgPool1d(2) over rows, [B*L/2, N]
@@ -167,3 +168,10 @@ hipError_t launch_randn_init(float* xt, long rows, int L, const uint64_t* seed_p
 hipError_t launch_set_seed(uint64_t* seed_ptr, uint64_t seed, int64_t first_sample, hipStream_t st);
 // one-time per-process kernel attribute setup (dynamic LDS > 64 KiB)
 hipError_t gemm_init();
+
+// ---------------------------------------------------------------- StyleExtractor spatial kernels (style.hip): NHWC, channels padded to Cp
+hipError_t launch_style_stem(int prec, const float* img, int B, int H, int W, const float* w, const float* bias, int Cp,
+                             void* out, hipStream_t st);   // -> [B, ceil(H/2), ceil(W/2), Cp]
+hipError_t launch_style_dw(int prec, const void* in, int B, int H, int W, int stride, const float* w, const float* bias,
+                           int Cp, void* out, hipStream_t st);
+hipError_t launch_style_pool(int prec, const void* in, int B, int H, int W, int C, int NB, float* out, hipStream_t st);

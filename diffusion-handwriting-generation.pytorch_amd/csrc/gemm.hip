@@ -272,6 +272,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
+      if (p.relu6_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 6.f);
+      }
       if (vblock) {   // [channel][row], rows past L zero
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<T*>(smem + (nl + r) * SVT + rl * ES) = from_f<T>(valid ? v[r] : 0.f);

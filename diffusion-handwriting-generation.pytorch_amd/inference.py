@@ -73,18 +73,70 @@ def infer(prompt: str, style_vector: torch.Tensor, model: DiffusionModel, diffus
     return out[0].detach().cpu().numpy()
 
 
-def load_style(source) -> torch.Tensor:
-    """The writer-style features of a prompt, [1,S,1280]: a tensor / array, or a file holding one (.npy, or .pt read with
-    weights_only=True).  The reference computes them from a handwriting image with torchvision's pretrained MobileNetV2
-    (text_style.py:43-59); that front end is not part of this build, so an image path is an error here."""
+def remove_whitespace(img: np.ndarray, thresh: float) -> np.ndarray:
+    """Crop to the rows / columns that hold a pixel darker than `thresh` (reference utils/preprocessing.py:47-62, the
+    `remove_middle=False` branch, including its exclusive upper bounds: the last inked row and column are dropped)."""
+    rows = np.nonzero(np.amin(img, axis=1) < thresh)[0]
+    cols = np.nonzero(np.amin(img, axis=0) < thresh)[0]
+    return img[rows[0]:rows[-1], cols[0]:cols[-1]]
+
+
+def _resize_cubic(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """uint8 bicubic resize with OpenCV's INTER_CUBIC conventions (Keys kernel a = -0.75, pixel centres aligned by
+    (dst + 0.5) * scale - 0.5, replicated border, no antialiasing), separable, float accumulation, round + saturate.
+    PARITY UNPINNED: cv2 is not importable here, its fixed-point rounding may differ in the last grey level."""
+    def taps(n_in, n_out):
+        x = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        x0 = np.floor(x).astype(np.int64)
+        t = x - x0
+        a = -0.75
+        w = np.stack([((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a,
+                      ((a + 2) * t - (a + 3)) * t * t + 1,
+                      ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1,
+                      ((a * (2 - t) - 5 * a) * (2 - t) + 8 * a) * (2 - t) - 4 * a], axis=1)
+        idx = np.clip(x0[:, None] + np.arange(-1, 3)[None, :], 0, n_in - 1)
+        return idx, w
+    f = img.astype(np.float64)
+    idx, w = taps(f.shape[1], out_w)
+    f = (f[:, idx] * w[None]).sum(-1)
+    idx, w = taps(f.shape[0], out_h)
+    f = (f[idx] * w[:, :, None]).sum(1)
+    return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+
+
+def read_img(path, height: int = 96) -> np.ndarray:
+    """Load a handwriting image as grey levels, crop the white margins and resize to `height` rows keeping the aspect
+    ratio (reference utils/io.py:98-115: cv2.imread(GRAYSCALE) -> remove_whitespace(thresh=127) -> cv2.resize(INTER_CUBIC))."""
+    from PIL import Image
+    img = np.asarray(Image.open(str(path)).convert("L"))
+    img = remove_whitespace(img, thresh=127)
+    h, w = img.shape
+    return _resize_cubic(img, height * w // h, height)
+
+
+_IMAGE_SUFFIXES = (".png", ".tif", ".tiff", ".jpg", ".jpeg", ".bmp", ".gif")
+_extractors = {}
+
+
+def load_style(source, style_weights=None) -> torch.Tensor:
+    """The writer-style features of a prompt, [1,S,1280].  `source` is what the reference's `infer` takes — the path of a
+    handwriting image, run through `read_img(source, 96)` and the StyleExtractor (inference.py:66-70, text_style.py:43-59;
+    `style_weights` = a local torchvision MobileNetV2 state_dict file, without it the extractor is random-initialised) —
+    or features computed elsewhere: a tensor / array, or a file holding one (.npy, or .pt read with weights_only=True)."""
     if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
         path = str(source)
+        if path.lower().endswith(_IMAGE_SUFFIXES):
+            from .style_extractor import StyleExtractor
+            key = str(style_weights)
+            if key not in _extractors:
+                _extractors[key] = StyleExtractor(style_weights, precision="fp32")
+            return _extractors[key](read_img(path, 96)[None, None, :])
         if path.endswith(".npy"):
             source = np.load(path, allow_pickle=False)
         elif path.endswith((".pt", ".pth")):
             source = torch.load(path, map_location="cpu", weights_only=True)
         else:
-            raise ValueError(f"{path}: pass the style features ([S,1280], .npy / .pt) — the StyleExtractor image front end is not built")
+            raise ValueError(f"{path}: pass a handwriting image ({', '.join(_IMAGE_SUFFIXES)}) or style features ([S,1280], .npy / .pt)")
     sv = torch.as_tensor(source, dtype=torch.float32)
     if sv.dim() == 2:
         sv = sv[None]
@@ -95,7 +147,7 @@ def load_style(source) -> torch.Tensor:
 
 def infer_file(prompt: str, source, config_path: str | None = None, checkpoint_path: str | None = None,
                experiment_path: str | None = None, output: str = "result", diffusion_mode: str = "new", *, precision: str = "bf16",
-               seed: int = 0, render: bool = True) -> np.ndarray:
+               seed: int = 0, render: bool = True, style_weights: str | None = None) -> np.ndarray:
     """The reference's command-line entry (inference.py:19-27) around this build's sampler: resolve config / checkpoint
     (directly or inside ``experiment_path``), load the model, sample one prompt, write ``./<output>.png``.
     Returns the [L,3] strokes."""
@@ -111,7 +163,7 @@ def infer_file(prompt: str, source, config_path: str | None = None, checkpoint_p
             checkpoint_path = str(ckpt) if ckpt else None
     if not config_path or not checkpoint_path:
         raise ValueError("Both config_path and checkpoint_path must be provided, either directly or via experiment_path.")
-    style = load_style(source)
+    style = load_style(source, style_weights)
     model = load_model(config_path, checkpoint_path, precision=precision, max_B=1, style_rows=style.shape[1])
     strokes = infer(prompt, style, model, diffusion_mode=diffusion_mode, seed=seed)
     if render:

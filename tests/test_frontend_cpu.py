@@ -70,8 +70,8 @@ def test_infer_file_argument_errors_mirror_the_reference(tmp_path):
         dhg_amd.infer_file("abc", np.zeros((14, 1280), np.float32))
     with pytest.raises(ValueError, match="config_path and checkpoint_path"):
         dhg_amd.infer_file("abc", np.zeros((14, 1280), np.float32), experiment_path=str(tmp_path))   # empty directory
-    with pytest.raises(ValueError, match="StyleExtractor"):
-        dhg_amd.load_style("writer.tif")
+    with pytest.raises(ValueError, match="handwriting image"):
+        dhg_amd.load_style("writer.xyz")
     with pytest.raises(ValueError, match="style features"):
         dhg_amd.load_style(np.zeros((14, 100), np.float32))
     f = tmp_path / "style.npy"
@@ -100,3 +100,26 @@ def test_polylines_match_the_reference_show_strokes(golden_dir):
     pos = np.cumsum(g["strokes"][:, :2], axis=0).T
     w, h = np.max(pos, axis=-1) - np.min(pos, axis=-1)
     assert np.allclose([w / h, 1.0], g["figsize"], rtol=1e-6)       # the figure size show_strokes asks for (scale = 1)
+
+
+def test_read_img_crops_the_margins_and_resizes_to_96_rows(tmp_path):
+    """reference utils/io.py:98-115 + utils/preprocessing.py:47-62: grey load, crop to the inked rows / columns (exclusive
+    upper bounds, as the reference slices), height 96 with width = 96 * w // h.  (cv2 is absent here: the cubic kernel
+    follows OpenCV's INTER_CUBIC conventions but is not pinned against it.)"""
+    from PIL import Image
+    img = np.full((60, 200), 255, np.uint8)
+    img[10:40, 20:150] = 255
+    img[10:40:3, 20:150:2] = 0            # ink inside rows 10..37, columns 20..148
+    Image.fromarray(img).save(tmp_path / "w.png")
+    cropped = dhg_amd.remove_whitespace(img, 127)
+    rows = np.nonzero(img.min(1) < 127)[0]
+    cols = np.nonzero(img.min(0) < 127)[0]
+    assert cropped.shape == (rows[-1] - rows[0], cols[-1] - cols[0])          # last inked row / column dropped
+    out = dhg_amd.read_img(tmp_path / "w.png", 96)
+    h, w = cropped.shape
+    assert out.dtype == np.uint8 and out.shape == (96, 96 * w // h)
+    # cubic interpolation of a constant image is that constant; of a step it stays within the overshoot bounds
+    from dhg_amd.inference import _resize_cubic
+    assert np.array_equal(_resize_cubic(np.full((7, 9), 93, np.uint8), 31, 20), np.full((20, 31), 93, np.uint8))
+    up = _resize_cubic(np.repeat(np.array([[0, 255]], np.uint8), 4, 0), 8, 4)
+    assert up[0, 0] == 0 and up[0, -1] == 255 and (np.diff(up[0].astype(int)) >= 0).all()
