@@ -207,7 +207,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
     }
-    layernorm_rows_1pass<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
+    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
     ENC_STAMP(11);
     if (act) {
 #pragma unroll

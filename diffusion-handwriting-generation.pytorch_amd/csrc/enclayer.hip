@@ -42,8 +42,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // keys per staged self-attention block: 128 when K [keys][DM] + V^T [DM][keys] fit beside the a2 tile (they overlay the
 // x3 / FFN tiles, which are written only after the attention), else 64
 template <typename T, int DM, int BM>
-constexpr int self_kbs() {
-  return (size_t)BM * tile_stride<T>(DM) + (size_t)128 * tile_stride<T>(DM) + (size_t)DM * (128 * sizeof(T) + 16) <= 160 * 1024 ? 128 : 64;
+constexpr size_t self_att_bytes(int kbs) { return (size_t)BM * tile_stride<T>(DM) + (size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + 16); }
+template <typename T, int DM, int BM>
+constexpr int self_kbs() {   // (32 keys: the fp32 parity mode, whose tiles are twice as wide)
+  return self_att_bytes<T, DM, BM>(128) <= 160 * 1024 ? 128 : (self_att_bytes<T, DM, BM>(64) <= 160 * 1024 ? 64 : 32);
 }
 template <typename T, int DM, int BM>
 constexpr size_t lds_bc_bytes() {
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  constexpr int RING = DM == 384 ? 15 : 24;   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
+  constexpr int RING = sizeof(T) == 4 ? 12 : (DM == 384 ? 15 : 24);   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -121,11 +123,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < UMAX; ++u) {
         const int h = hs + u * HS;
         if (h < H) {
+          constexpr int SUB = KBS < 64 ? KBS : 64;
 #pragma unroll
-          for (int sub = 0; sub < KBS; sub += 64)
+          for (int sub = 0; sub < KBS; sub += SUB)
             if (kb + sub < p.Lk)
-              attn_block_lds<T, 64, 64>(qf[u], KT + (sub + l15) * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + (sub + 4 * g) * ES, SV,
-                                        kb + sub, 0u, p.Lk, mr[u], lr[u], o[u]);
+              attn_block_lds<T, 64, SUB>(qf[u], KT + (sub + l15) * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + (sub + 4 * g) * ES, SV,
+                                         kb + sub, 0u, p.Lk, mr[u], lr[u], o[u]);
         }
       }
       if (kb < 3 * KBS) STAMP(27 + 2 * (kb / KBS));
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
     }
     STAMP(18);
-    layernorm_rows_1pass<MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
     if (act) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < MT; ++j)
         acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
   }
-  layernorm_rows_1pass<MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
+  ln_rows<T, MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
   // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
   if (act) {
 #pragma unroll
@@ -313,22 +316,28 @@ hipError_t launch_bc(const EncLayerParams& p, const EncChain& nx, hipStream_t st
 
 // variants with a compiled chain: mode 1 for the attention layers (DM = 384, tiles up to 32 rows: LDS), mode 2 for enc5
 template <typename T, int DM, int BM>
-constexpr bool has_chain(int mode) {   // (LDS: the chained layer's text K/V block sits behind the three stage tiles)
-  return (mode == 1 && DM == 384 && BM <= 32) || (mode == 2 && DM == 256 && BM == 32);
+constexpr bool has_chain(int mode) {   // (LDS: the chained layer's text K/V block sits behind the three stage tiles; bf16 only)
+  return sizeof(T) == 2 && ((mode == 1 && DM == 384 && BM <= 32) || (mode == 2 && DM == 256 && BM == 32));
 }
 
 template <typename T, int DM, int BM>
+constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, DM, BM>(); }
+// does the (element type, width, row tile) combination fit the 160 KiB of LDS in both halves of the layer?
+template <typename T, int DM, int BM>
+constexpr bool fits() { return lds_a_bytes<T, DM, BM>() <= 160 * 1024 && lds_bc_bytes<T, DM, BM>() <= 160 * 1024 && (DM % 128 == 0 || BM >= 32); }
+
+template <typename T, int DM, int BM>
 hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
+  if constexpr (!fits<T, DM, BM>()) {
+    return hipErrorInvalidValue;
+  } else {
   const int tiles = (p.Lk + BM - 1) / BM;
-  const size_t red = 2 * 8 * BM * sizeof(float);
   if (which == 0) {
-    const size_t lds = (size_t)2 * BM * tile_stride<T>(DM) + red + enc_a_text_kv_bytes<T, DM, BM>();
+    constexpr size_t lds = lds_a_bytes<T, DM, BM>();
     hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
     return hipGetLastError();
   }
-  if constexpr (lds_bc_bytes<T, DM, BM>() > 160 * 1024) {
-    return hipErrorInvalidValue;
-  } else {
+  {
     if (chain && chain->mode) {
       if (chain->a.x) return hipErrorInvalidValue;   // the chained layer reads its x tile from LDS
       if constexpr (has_chain<T, DM, BM>(1)) { if (chain->mode == 1 && chain->a.d == DM) return launch_bc<T, DM, BM, 1>(p, *chain, st); }
@@ -336,6 +345,7 @@ hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st, const
       return hipErrorInvalidValue;
     }
     return launch_bc<T, DM, BM, 0>(p, EncChain{}, st);
+  }
   }
 }
 
@@ -346,10 +356,10 @@ hipError_t attr_bc() {
 
 template <typename T, int DM, int BM>
 hipError_t attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM, BM>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  if constexpr (lds_bc_bytes<T, DM, BM>() <= 160 * 1024) {
+  if constexpr (fits<T, DM, BM>()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_a_kernel<T, DM, BM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     if ((e = attr_bc<T, DM, BM, 0>()) != hipSuccess) return e;
     if constexpr (has_chain<T, DM, BM>(1)) { if ((e = attr_bc<T, DM, BM, 1>()) != hipSuccess) return e; }
     if constexpr (has_chain<T, DM, BM>(2)) { if ((e = attr_bc<T, DM, BM, 2>()) != hipSuccess) return e; }
@@ -369,12 +379,9 @@ int pick_bm(int B, int Lk, int bm_min = 0) {
   if ((long)B * ((Lk + 63) / 64) < target) bm = 32;
   if (DM % 128 == 0 && (long)B * ((Lk + 31) / 32) < target) bm = 16;   // (the 4x2 wave layout of DM=192 needs >= 32 rows)
   if (force) bm = force;
-  // LDS budget (160 KiB) of enc_bc: the three stage tiles, or the a2 tile + one 64-key K/V block; shrink the row tile until it fits
-  auto lds_bc = [](int m) {
-    return std::max((size_t)3 * m * tile_stride<T>(DM) + 2 * 8 * m * sizeof(float),
-                    (size_t)m * tile_stride<T>(DM) + (size_t)64 * tile_stride<T>(DM) + (size_t)DM * (64 * sizeof(T) + 16));
-  };
-  while (bm > 16 && lds_bc(bm) > 160 * 1024) bm /= 2;
+  // LDS budget (160 KiB) of both halves: shrink the row tile until the combination fits (fp32 tiles are twice as wide)
+  auto ok = [](int m) { return m == 64 ? fits<T, DM, 64>() : m == 32 ? fits<T, DM, 32>() : fits<T, DM, 16>(); };
+  while (bm > 16 && !ok(bm)) bm /= 2;
   if (DM % 128 != 0 && bm < 32) bm = 32;
   if (bm < bm_min) bm = bm_min;
   return bm == 16 || bm == 32 ? bm : 64;
@@ -398,11 +405,18 @@ hipError_t enclayer_init() {
   if ((e = attr<bf16_t, 256, 32>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 384, 32>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 256, 16>()) != hipSuccess) return e;
-  return attr<bf16_t, 384, 16>();
+  if ((e = attr<bf16_t, 384, 16>()) != hipSuccess) return e;
+  // fp32 parity mode: the same kernels (exact-f32 MFMA), the row tiles that fit LDS
+  if ((e = attr<float, 192, 64>()) != hipSuccess) return e;
+  if ((e = attr<float, 192, 32>()) != hipSuccess) return e;
+  if ((e = attr<float, 256, 32>()) != hipSuccess) return e;
+  if ((e = attr<float, 256, 16>()) != hipSuccess) return e;
+  return attr<float, 384, 16>();
 }
 
 bool enclayer_supported(int prec, int d, int heads) {
-  return prec == PREC_BF16 && (d == 192 || d == 256 || d == 384) && heads * 64 == d;
+  const bool f32_fused = !(getenv("DHW_FUSE_F32") && atoi(getenv("DHW_FUSE_F32")) == 0);   // A/B: one launch per GEMM in fp32
+  return (prec == PREC_BF16 || (prec == PREC_F32 && f32_fused)) && (d == 192 || d == 256 || d == 384) && heads * 64 == d;
 }
 
 // which: 0 = enc_a (cross attention half + q/k/v projection), 1 = enc_bc (self attention + FFN half)
@@ -415,6 +429,15 @@ bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_ne
 
 hipError_t launch_enclayer(int prec, const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
   if (!enclayer_supported(prec, p.d, p.heads) || (p.pool && (p.Lk & 1)) || (chain && chain->mode && which != 1)) return hipErrorInvalidValue;
+  if (prec == PREC_F32) {
+    if (chain && chain->mode) return hipErrorInvalidValue;
+    switch (p.d) {
+      case 192: return launch_bm<float, 192>(p, which, st, nullptr);
+      case 256: return launch_bm<float, 256>(p, which, st, nullptr);
+      case 384: return launch_bm<float, 384>(p, which, st, nullptr);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (p.d) {
     case 192: return launch_bm<bf16_t, 192>(p, which, st, chain);
     case 256: return launch_bm<bf16_t, 256>(p, which, st, chain);

@@ -278,3 +278,11 @@ DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int 
     for (int i = 0; i < NT; ++i) acc[i][j] = (acc[i][j] - mean) * rstd;
   }
 }
+
+// LayerNorm flavour by element type: the fp32 parity mode keeps the two-pass form (mean, then centred squares), bf16 the
+// one-barrier E[x^2] - mean^2 form.
+template <typename T, int MT, int NT, int WN, int ROWS>
+DHW_DEV void ln_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true) {
+  if constexpr (sizeof(T) == 4) layernorm_rows<MT, NT, WN, ROWS>(acc, red, wn, row0, lane, N, act);
+  else layernorm_rows_1pass<MT, NT, WN, ROWS>(acc, red, wn, row0, lane, N, act);
+}
