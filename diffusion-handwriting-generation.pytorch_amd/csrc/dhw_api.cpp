@@ -211,6 +211,7 @@ struct dhw_handle {
   bool fuse_up = true;          // decoder ConvBlocks evaluate Upsample + skip_conv while staging (env DHW_FUSE_UP=0 -> separate GEMM)
   bool chain = true;            // row-local stages continue across layer boundaries inside one launch (env DHW_CHAIN=0 -> off)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
+  bool fuse_text = true;        // fused text-side kernels (textside.hip; env DHW_FUSE_TEXT=0 -> generic GEMM / attention launches)
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
   float* d_style_stage = nullptr;
@@ -448,13 +449,19 @@ int ensure_plane(dhw_handle* h, Workspace& w, long steps, long B) {
   const int c2 = d.c2, c3 = d.c3, dt = 2 * c2;
   int rc;
 #define AA(name, rows, cols) if ((rc = act_alloc(h, w, name, rows, cols))) return rc
-  AA("s1.T", n * S5, dt); AA("k8.T", n * S5, dt); AA("vt8.T", n * dt, h->lpadS);
-  AA("t1.T", n * Lt, dt); AA("q8.T", n * Lt, dt); AA("a8.T", n * Lt, dt); AA("t2.T", n * Lt, dt);
-  AA("tf_h.T", n * Lt, 2 * dt); AA("text_out.T", n * Lt, dt);
+  // with the fused text-side kernels (every call of this handle qualifies) only text_out and the layers' K / V^T exist
+  const bool fused = h->fuse && h->fuse_text && textside_supported(h->prec, (int)Lt, (int)S5, dt);
+  if (!fused) {
+    AA("s1.T", n * S5, dt); AA("k8.T", n * S5, dt); AA("vt8.T", n * dt, h->lpadS);
+    AA("t1.T", n * Lt, dt); AA("q8.T", n * Lt, dt); AA("a8.T", n * Lt, dt); AA("t2.T", n * Lt, dt);
+    AA("tf_h.T", n * Lt, 2 * dt);
+  }
+  AA("text_out.T", n * Lt, dt);
   std::vector<std::pair<std::string, int>> els = {{"enc3", c2}, {"enc5", c3}};
   for (int i = 0; i < d.num_layers; ++i) els.push_back({"att_layers." + std::to_string(i), dt});
   for (auto& e : els) {
-    AA(e.first + ".tl.T", n * Lt, e.second); AA(e.first + ".k1.T", n * Lt, e.second); AA(e.first + ".vt1.T", n * e.second, h->lpadT);
+    if (!fused) AA(e.first + ".tl.T", n * Lt, e.second);
+    AA(e.first + ".k1.T", n * Lt, e.second); AA(e.first + ".vt1.T", n * e.second, h->lpadT);
   }
 #undef AA
   w.plane_cap = n;   // (a grown plane leaks the smaller one until destroy)
@@ -880,6 +887,42 @@ void text_style_dynamic(Ctx& c) {
   const float* bt = c.film + h->film_tot;
   const std::string& x = c.sfx;
   const int in_B = c.in_B ? c.in_B : c.B;
+  if (h->fuse && h->fuse_text && textside_supported(h->prec, c.Lt, c.S5, dt)) {
+    // one workgroup per (step, prompt) pair, every intermediate in LDS (textside.hip)
+    TextStyleParams q{};
+    q.n = c.B; q.in_B = in_B; q.Lt = c.Lt; q.S5 = c.S5;
+    q.sty_n = BUF(c, "sty_n"); q.t_n = BUF(c, "t_n");
+    q.film = c.film; q.film_bs = c.film_bs; q.film_div = c.film_div; q.film_tot = h->film_tot;
+    q.f1 = h->f_ts1; q.f2 = h->f_ts2; q.f3 = h->f_ts3; q.f4 = h->f_ts4;
+    q.w_q8 = h->w_q8; q.w_kv8 = h->w_kv8; q.w_d8 = h->w_d8; q.w_tf1 = h->w_tf1; q.w_tf3 = h->w_tf3;
+    q.b_q8 = h->b_q8; q.b_kv8 = h->b_kv8; q.b_d8 = h->b_d8; q.b_tf1 = h->b_tf1; q.b_tf3 = h->b_tf3;
+    q.text_out = BUF(c, "text_out" + x);
+    if (!c.err) {
+      const double n = c.B, ddt = dt;
+      Launch l(h, c.st, "ts.fused", n * (2.0 * c.S5 * ddt * 2 * ddt + 2.0 * c.Lt * ddt * ddt * 2 + 4.0 * c.Lt * c.S5 * ddt + 2.0 * c.Lt * ddt * 2 * ddt * 2),
+               n * c.Lt * ddt * h->es + (double)in_B * (c.S5 + c.Lt) * ddt * h->es + 8.0 * ddt * ddt * h->es);
+      hipError_t e = launch_text_style(h->prec, q, c.st);
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "text_style fused: %s", hipGetErrorString(e));
+    }
+    if (x.empty()) tap(c, "text_style_model", "text_out", c.Lt, dt);
+    const char* nm[2] = {"enc3", "enc5"};
+    for (size_t i = 0; i < h->el.size() && !c.err; ++i) {
+      const std::string ln = i < 2 ? nm[i] : "att_layers." + std::to_string(i - 2);
+      const EncLayerW& w = h->el[i];
+      TextLayerParams t{};
+      t.n = c.B; t.Lt = c.Lt; t.d = w.d;
+      t.text_out = BUF(c, "text_out" + x);
+      t.w_td = w.w_td; t.b_td = w.b_td;
+      t.film = c.film; t.film_bs = c.film_bs; t.film_div = c.film_div; t.film_tot = h->film_tot; t.f0 = w.f0;
+      t.w_kv = w.w_kv1; t.b_kv = w.b_kv1; t.pb_k1 = w.pb_k1;
+      t.k1 = BUF(c, ln + ".k1" + x); t.vt1 = BUF(c, ln + ".vt1" + x); t.lpadT = h->lpadT;
+      const double n = c.B, dd = w.d;
+      Launch l(h, c.st, "enc.text_fused", n * c.Lt * (2.0 * dt * dd + 4.0 * dd * dd), n * c.Lt * (dt + 2.0 * dd) * h->es + (dt * dd + 2.0 * dd * dd) * h->es);
+      hipError_t e = launch_text_layer(h->prec, t, c.st);
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "text layer %s: %s", ln.c_str(), hipGetErrorString(e));
+    }
+    return;
+  }
   RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(c, "sty_n"), in_B, c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, c.film_div, BUF(c, "s1" + x), c.st));
   RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(c, "t_n"), in_B, c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, c.film_div, BUF(c, "t1" + x), c.st));
   {
@@ -1126,11 +1169,13 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
     if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
   if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
   if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
+  if (const char* e = getenv("DHW_FUSE_TEXT")) h->fuse_text = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
   if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!rc && textside_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) { g_err = h->err; dhw_destroy(h); return rc; }
   *out = h;

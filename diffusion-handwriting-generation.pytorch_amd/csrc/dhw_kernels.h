@@ -175,3 +175,31 @@ hipError_t launch_style_stem(int prec, const float* img, int B, int H, int W, co
 hipError_t launch_style_dw(int prec, const void* in, int B, int H, int W, int stride, const float* w, const float* bias,
                            int Cp, void* out, hipStream_t st);
 hipError_t launch_style_pool(int prec, const void* in, int B, int H, int W, int C, int NB, float* out, hipStream_t st);
+
+// ---------------------------------------------------------------- fused text side (textside.hip): one workgroup per (step, prompt) pair
+struct TextStyleParams {
+  int n;                  // (sampler step, prompt) pairs of this launch
+  int in_B;               // prompts behind the sigma-independent inputs: pair i reads prompt i % in_B
+  int Lt, S5;             // tokens (<= 32), style rows (<= 80)
+  const void* sty_n;      // LN(style_ffn(style))  [in_B][S5][384]
+  const void* t_n;        // LN(emb(text))         [in_B][Lt][384]
+  const float* film; long film_bs; int film_div; int film_tot;   // gamma row of pair i = film + (i / film_div) * film_bs, beta = gamma + film_tot
+  int f1, f2, f3, f4;     // FiLM offsets of text_style_model.affine1..4
+  const void *w_q8, *w_kv8, *w_d8, *w_tf1, *w_tf3;   // packed as for the GEMM kernel ([384x384], [768x384] K|V, [384x384], [768x384], [384x768])
+  const float *b_q8, *b_kv8, *b_d8, *b_tf1, *b_tf3;
+  void* text_out;         // [n][Lt][384]
+};
+struct TextLayerParams {
+  int n, Lt, d;           // pairs, tokens (<= 32), layer width (192 / 256 / 384)
+  const void* text_out;   // [n][Lt][384]
+  const void* w_td; const float* b_td;       // text_dense [d x 384]
+  const float* film; long film_bs; int film_div; int film_tot; int f0;
+  const void* w_kv; const float* b_kv;       // stacked K|V projection of the cross attention [2d x d]
+  const float* pb_k1;     // PE·Wk table [>= Lt][d]
+  void* k1;               // [n][Lt][d]
+  void* vt1; int lpadT;   // [n][d][lpadT], keys contiguous
+};
+bool textside_supported(int prec, int Lt, int S5, int dt);
+hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st);
+hipError_t launch_text_layer(int prec, const TextLayerParams& p, hipStream_t st);
+hipError_t textside_init();
