@@ -121,6 +121,35 @@ DHW_DEV void staged_copy(int total, int tid, int nthreads, SrcF src, DstF dst) {
   }
 }
 
+// The same copy split in two: load() requests this thread's <= U pieces, store() writes them to LDS.  Several tiles staged
+// by one workgroup issue ALL their loads before the first store, so they cost one memory round trip together instead
+// of one each (enc_a staged x, then the text keys, then the text values: three dependent L2 / HBM latencies).
+// Requires total <= nthreads * U.
+template <int U>
+struct CopyRegs {
+  uint4 v[U];
+  template <typename SrcF>
+  DHW_DEV void load(int total, int tid, int nthreads, SrcF src) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = tid + u * nthreads;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (id < total) {
+        const uint4* sp = src(id);
+        if (sp) v[u] = *sp;
+      }
+    }
+  }
+  template <typename DstF>
+  DHW_DEV void store(int total, int tid, int nthreads, DstF dst) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = tid + u * nthreads;
+      if (id < total) *dst(id) = v[u];
+    }
+  }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue
 // (s_waitcnt vmcnt(0)), which would stall every wave until the NEXT stage's prefetched weight fragments have
 // landed; the fused kernels exchange data between waves through LDS only, so lgkmcnt(0) + s_barrier suffices

@@ -98,14 +98,33 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   WRing<T, NT> ring;
   EpiParams<NT> ep;
   ENC_STAMP(0);
-  if (p.x) stage_rows<T, BM>(XR, S, reinterpret_cast<const T*>(p.x), DM, b, p.Lk, m0, tid, 512);
-  // the first block of text keys / values (usually all of them) is staged here too: its latency hides behind q1
+  // x tile, first block of text keys and of text values (usually all of them): every load is requested before the first
+  // LDS store, so the three tiles cost one memory round trip together; its latency hides behind nothing (the q1 GEMM
+  // needs x), the K / V tiles are only needed after q1.
   constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + 16;
+  constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBC / EPV;
+  constexpr int UX = (BM * CPR + 511) / 512, UK = (KBC * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
   char* KT = m.KT;
   char* VT = m.VT;
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
-  attn_stage_kv<T, KBC>(KT, SKC, VT, SVC, k1s, DM, v1s, p.lpadT, DM, 0, p.Lt, tid, 512);
+  {
+    CopyRegs<UX> cx;
+    CopyRegs<UK> ck;
+    CopyRegs<UV> cv;
+    const T* xs = reinterpret_cast<const T*>(p.x);
+    if (p.x)
+      cx.load(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                                return m0 + r < p.Lk ? reinterpret_cast<const uint4*>(xs + (size_t)(b * p.Lk + m0 + r) * DM + cc * EPV) : nullptr; });
+    ck.load(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                               return r < p.Lt ? reinterpret_cast<const uint4*>(k1s + (size_t)r * DM + cc * EPV) : nullptr; });
+    cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                                              return (part + 1) * EPV <= p.lpadT ? reinterpret_cast<const uint4*>(v1s + (size_t)ch * p.lpadT + part * EPV) : nullptr; });
+    if (p.x)
+      cx.store(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(XR + r * S + cc * 16); });
+    ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); });
+    cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SVC + part * 16); });
+  }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
   PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
   pad.load(trow, 0, p.Lt);
