@@ -23,6 +23,10 @@ class DhwDims(C.Structure):
                 ("precision", C.c_int)]
 
 
+class ConvBlockWeights(C.Structure):   # include/dhw_train.h dhw_convblock_weights (HOST pointers) / dhw_convblock_grads (DEVICE pointers)
+    _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "fc_w", "fc_b", "skip_w", "skip_b", "film_w", "film_b")]
+
+
 class DhwError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libdhw_hip error {code}: {msg}")
@@ -65,6 +69,14 @@ SIGNATURES = {
     "dhw_style_debug_features": (C.c_int64, [_P, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
     "dhw_style_last_error": (C.c_char_p, [_P]),
     "dhw_style_destroy": (None, [_P]),
+    # include/dhw_train.h
+    "dhw_train_perturb": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "dhw_train_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dhw_train_adam": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P, _P]),
+    "dhw_train_convblock": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(ConvBlockWeights), _P, _P, _P,
+                                      C.POINTER(ConvBlockWeights), _P]),
+    "dhw_train_last_error": (C.c_char_p, []),
     "dhw_debug_randn": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 

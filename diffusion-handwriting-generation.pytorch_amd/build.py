@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdhw_hip.so")
-SOURCES = ["gemm.hip", "convblock.hip", "enclayer.hip", "attn.hip", "misc.hip", "style.hip", "textside.hip", "dhw_api.cpp", "dhw_style_api.cpp"]
+SOURCES = ["gemm.hip", "convblock.hip", "enclayer.hip", "attn.hip", "misc.hip", "style.hip", "textside.hip", "train.hip", "dhw_api.cpp", "dhw_style_api.cpp", "dhw_train_api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -30,7 +30,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers += [os.path.join(HERE, "..", "include", f) for f in ("dhw.h", "dhw_debug.h", "dhw_style.h")]
+    headers += [os.path.join(HERE, "..", "include", f) for f in ("dhw.h", "dhw_debug.h", "dhw_style.h", "dhw_train.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -203,3 +203,20 @@ bool textside_supported(int prec, int Lt, int S5, int dt);
 hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st);
 hipError_t launch_text_layer(int prec, const TextLayerParams& p, hipStream_t st);
 hipError_t textside_init();
+
+// ---------------------------------------------------------------- training step, first slice (train.hip); fp32, rows C-last
+hipError_t launch_perturb(const float* x, const float* eps, const float* alphas, int B, int L, float* out, hipStream_t st);
+hipError_t launch_loss(const float* eps, const float* pred, const float* pen, const float* pen_pred, const float* alphas, int B, int L,
+                       float* out3, float* d_pred, float* d_pen, hipStream_t st);
+hipError_t launch_sqnorm(const float* g, long n, float* out, hipStream_t st);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                       const float* sqnorm, float max_norm, hipStream_t st);
+hipError_t launch_film_silu_fwd(const float* u, const float* film, long film_bs, int goff, int boff, int B, int L, int C, float* a, float* h, hipStream_t st);
+hipError_t launch_film_bwd(const float* d, const float* a, const float* u, const float* film, long film_bs, int goff, int B, int L, int C, int act,
+                           float* du, float* dfilm, long dfilm_bs, int dgoff, int dboff, hipStream_t st);
+hipError_t launch_silu_bwd_add(const float* d_sx, const float* x, long n, float* dx, hipStream_t st);
+hipError_t launch_silu_fwd(const float* x, long n, float* out, hipStream_t st);
+hipError_t launch_add(const float* a, const float* b, long n, float* out, hipStream_t st);
+hipError_t launch_colsum(const float* dy, long rows, int C, float* db, hipStream_t st);
+hipError_t launch_wgrad(const float* dy, const float* x, int B, int L, int Cout, int Cin, int taps, float* dw, hipStream_t st);
+hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const float* wcat, int B, int cols, float* dw, float* db, float* dsigma, hipStream_t st);

@@ -1,0 +1,224 @@
+// dhw_train_api.cpp — C-ABI of the training step's first slice (include/dhw_train.h): loss / perturbation / optimizer
+// kernels and the ConvBlock forward + backward built from the generic MFMA GEMM (forward and data-gradient
+// convolutions, the latter with transposed / tap-flipped packed weights) and the kernels of train.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dhw_train.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+std::string g_terr;
+
+int tfail(int code, const char* fmt, ...) {
+  char tmp[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  g_terr = tmp;
+  return code;
+}
+#define THIP(call)                                                                            \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return tfail(DHW_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));  \
+  } while (0)
+
+// scratch allocations of one dhw_train_convblock call, released on every exit path
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() {
+    hipDeviceSynchronize();
+    for (void* p : ptrs) hipFree(p);
+  }
+  float* f32(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 4) * sizeof(float)) != hipSuccess) return nullptr;
+    hipMemset(p, 0, (n ? n : 4) * sizeof(float));
+    ptrs.push_back(p);
+    return (float*)p;
+  }
+  float* upload(const std::vector<float>& v) {
+    float* p = f32(v.size());
+    if (p && hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return p;
+  }
+  // row-major Wf[N][K] -> MFMA-fragment order [N/16][K/32][64 lanes][8], fp32 (as dhw_api.cpp upload_packed)
+  float* packed(const std::vector<float>& wf, int N, int K) {
+    std::vector<float> pk((size_t)N * K);
+    size_t o = 0;
+    for (int nt = 0; nt < N / 16; ++nt)
+      for (int kc = 0; kc < K / 32; ++kc)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) pk[o++] = wf[(size_t)(nt * 16 + (l & 15)) * K + kc * 32 + 8 * (l >> 4) + j];
+    return upload(pk);
+  }
+};
+
+// forward convolution matrix: Wf[co][tap * cin + ci] = W[co][ci][tap]
+std::vector<float> fwd_matrix(const float* w, int cout, int cin, int taps) {
+  std::vector<float> f((size_t)cout * cin * taps);
+  for (int o = 0; o < cout; ++o)
+    for (int i = 0; i < cin; ++i)
+      for (int t = 0; t < taps; ++t) f[(size_t)o * cin * taps + t * cin + i] = w[((size_t)o * cin + i) * taps + t];
+  return f;
+}
+// data-gradient matrix: dX[r][ci] = sum_{tap', co} dY[r + tap' - 1][co] * W[co][ci][taps - 1 - tap']  =>  Wd[ci][tap' * cout + co]
+std::vector<float> dgrad_matrix(const float* w, int cout, int cin, int taps) {
+  std::vector<float> f((size_t)cout * cin * taps);
+  for (int i = 0; i < cin; ++i)
+    for (int t = 0; t < taps; ++t)
+      for (int o = 0; o < cout; ++o) f[(size_t)i * cout * taps + t * cout + o] = w[((size_t)o * cin + i) * taps + (taps - 1 - t)];
+  return f;
+}
+
+int conv_gemm(const float* in, int B, int L, int C, int taps, const float* w_packed, const float* bias, int N, float* out, hipStream_t st) {
+  GemmParams p{};
+  p.nseg = 1;
+  p.seg[0] = GemmSeg{in, w_packed, C, taps, 0};
+  p.B = B;
+  p.L = L;
+  p.N = N;
+  p.n_store = N;
+  p.bias0 = bias;
+  p.film_div = 1;
+  p.out = out;
+  hipError_t e = launch_gemm(PREC_F32, p, st);
+  if (e != hipSuccess) return tfail(DHW_ERR_HIP, "conv gemm %d x%d -> %d: %s", C, taps, N, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dhw_train_last_error(void) { return g_terr.c_str(); }
+
+int dhw_train_perturb(const float* x, const float* eps, const float* alphas, int B, int L, float* out, void* hip_stream) {
+  if (!x || !eps || !alphas || !out || B < 1 || L < 1) return tfail(DHW_ERR_ARG, "dhw_train_perturb: bad argument");
+  THIP(launch_perturb(x, eps, alphas, B, L, out, (hipStream_t)hip_stream));
+  return 0;
+}
+
+int dhw_train_loss(const float* eps, const float* score_pred, const float* pen, const float* pen_pred, const float* alphas, int B, int L,
+                   float* out3, float* d_score, float* d_pen_pred, void* hip_stream) {
+  if (!eps || !score_pred || !pen || !pen_pred || !alphas || !out3 || B < 1 || L < 1) return tfail(DHW_ERR_ARG, "dhw_train_loss: bad argument");
+  THIP(launch_loss(eps, score_pred, pen, pen_pred, alphas, B, L, out3, d_score, d_pen_pred, (hipStream_t)hip_stream));
+  return 0;
+}
+
+int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float max_norm, float* grad_norm_out, void* hip_stream) {
+  if (nbuf < 1 || !p || !g || !m || !v || !n || step < 1) return tfail(DHW_ERR_ARG, "dhw_train_adam: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  float* sq = nullptr;
+  if (max_norm > 0.f || grad_norm_out) {
+    THIP(hipMalloc((void**)&sq, sizeof(float)));
+    THIP(hipMemsetAsync(sq, 0, sizeof(float), st));
+    for (int i = 0; i < nbuf; ++i) THIP(launch_sqnorm(g[i], n[i], sq, st));
+  }
+  for (int i = 0; i < nbuf; ++i)
+    THIP(launch_adam(p[i], g[i], m[i], v[i], n[i], lr, beta1, beta2, eps, weight_decay, step, max_norm > 0.f ? sq : nullptr, max_norm, st));
+  if (sq) {
+    if (grad_norm_out) THIP(hipMemcpyAsync(grad_norm_out, sq, sizeof(float), hipMemcpyDeviceToDevice, st));   // (squared norm)
+    THIP(hipStreamSynchronize(st));
+    THIP(hipFree(sq));
+  }
+  return 0;
+}
+
+int dhw_train_convblock(int device, int B, int L, int cin, int cout, const float* x, const float* sigma, const float* dout,
+                        const dhw_convblock_weights* w, float* out, float* dx, float* dsigma, const dhw_convblock_grads* g, void* hip_stream) {
+  if (!x || !sigma || !dout || !w || !out || !dx || !dsigma || !g) return tfail(DHW_ERR_ARG, "dhw_train_convblock: null pointer");
+  const int c1 = cout / 2;
+  if (B < 1 || L < 2 || (L & 1) || cin % 32 || c1 % 32 || cout % 64) return tfail(DHW_ERR_ARG, "dhw_train_convblock: unsupported shape B=%d L=%d %d -> %d", B, L, cin, cout);
+  THIP(hipSetDevice(device));
+  if (gemm_init() != hipSuccess) return tfail(DHW_ERR_HIP, "kernel attribute setup failed");
+  hipStream_t st = (hipStream_t)hip_stream;
+  Scratch s;
+  const long rows = (long)B * L, slack = 64;
+  const int tot = c1 + 2 * cout, cols = 2 * tot;          // FiLM table columns: gamma1|gamma2|gamma3|beta1|beta2|beta3
+  const int go[3] = {0, c1, c1 + cout}, bo[3] = {tot, tot + c1, tot + c1 + cout};
+
+  // ---- weights: forward and data-gradient matrices in MFMA-fragment order
+  float* wf1 = s.packed(fwd_matrix(w->conv1_w, c1, cin, 3), c1, 3 * cin);
+  float* wf2 = s.packed(fwd_matrix(w->conv2_w, cout, c1, 3), cout, 3 * c1);
+  float* wff = s.packed(fwd_matrix(w->fc_w, cout, cout, 1), cout, cout);
+  float* wfs = s.packed(fwd_matrix(w->skip_w, cout, cin, 3), cout, 3 * cin);
+  float* wd1 = s.packed(dgrad_matrix(w->conv1_w, c1, cin, 3), cin, 3 * c1);
+  float* wd2 = s.packed(dgrad_matrix(w->conv2_w, cout, c1, 3), c1, 3 * cout);
+  float* wdf = s.packed(dgrad_matrix(w->fc_w, cout, cout, 1), cout, cout);
+  float* wds = s.packed(dgrad_matrix(w->skip_w, cout, cin, 3), cin, 3 * cout);
+  float* b1 = s.upload(std::vector<float>(w->conv1_b, w->conv1_b + c1));
+  float* b2 = s.upload(std::vector<float>(w->conv2_b, w->conv2_b + cout));
+  float* bf = s.upload(std::vector<float>(w->fc_b, w->fc_b + cout));
+  float* bsk = s.upload(std::vector<float>(w->skip_b, w->skip_b + cout));
+  float* wcat = s.upload(std::vector<float>(w->film_w, w->film_w + (size_t)cols * 32));
+  float* bcat = s.upload(std::vector<float>(w->film_b, w->film_b + cols));
+  // ---- activations kept for the backward pass (every buffer with slack rows for the GEMM tiles)
+  auto act = [&](int C) { return s.f32((size_t)(rows + slack) * C); };
+  float *xs = act(cin), *sx = act(cin), *u1 = act(c1), *a1 = act(c1), *h1 = act(c1), *u2 = act(cout), *a2 = act(cout), *h2 = act(cout),
+        *u3 = act(cout), *a3 = act(cout), *sk = act(cout), *dos = act(cout);
+  float *du3 = act(cout), *dh2 = act(cout), *du2 = act(cout), *dh1 = act(c1), *du1 = act(c1), *dsx = act(cin), *dxs = act(cin);
+  float* film = s.f32((size_t)B * cols);
+  float* dfilm = s.f32((size_t)B * cols);
+  float* zb = s.f32(cout);   // zero bias for the data-gradient convolutions
+  if (!wf1 || !wf2 || !wff || !wfs || !wd1 || !wd2 || !wdf || !wds || !b1 || !b2 || !bf || !bsk || !wcat || !bcat || !dxs || !film || !dfilm || !zb)
+    return tfail(DHW_ERR_HIP, "dhw_train_convblock: out of device memory");
+  THIP(hipMemcpyAsync(xs, x, rows * cin * 4, hipMemcpyDeviceToDevice, st));      // (the caller's buffers carry no slack rows)
+  THIP(hipMemcpyAsync(dos, dout, rows * cout * 4, hipMemcpyDeviceToDevice, st));
+  int rc;
+
+  // ---- forward (cnn.py:64-87), every pre-activation kept
+  THIP(launch_film(sigma, B, wcat, bcat, cols, film, st));
+  THIP(launch_silu_fwd(xs, rows * cin, sx, st));
+  if ((rc = conv_gemm(sx, B, L, cin, 3, wf1, b1, c1, u1, st))) return rc;
+  THIP(launch_film_silu_fwd(u1, film, cols, go[0], bo[0], B, L, c1, a1, h1, st));
+  if ((rc = conv_gemm(h1, B, L, c1, 3, wf2, b2, cout, u2, st))) return rc;
+  THIP(launch_film_silu_fwd(u2, film, cols, go[1], bo[1], B, L, cout, a2, h2, st));
+  if ((rc = conv_gemm(h2, B, L, cout, 1, wff, bf, cout, u3, st))) return rc;
+  THIP(launch_film_silu_fwd(u3, film, cols, go[2], bo[2], B, L, cout, a3, nullptr, st));
+  if ((rc = conv_gemm(xs, B, L, cin, 3, wfs, bsk, cout, sk, st))) return rc;
+  THIP(launch_add(a3, sk, rows * cout, out, st));
+
+  // ---- backward
+  const size_t n1 = (size_t)c1 * cin * 3, n2 = (size_t)cout * c1 * 3, nf = (size_t)cout * cout, ns = (size_t)cout * cin * 3;
+  THIP(hipMemsetAsync(g->conv1_w, 0, n1 * 4, st)); THIP(hipMemsetAsync(g->conv1_b, 0, c1 * 4, st));
+  THIP(hipMemsetAsync(g->conv2_w, 0, n2 * 4, st)); THIP(hipMemsetAsync(g->conv2_b, 0, cout * 4, st));
+  THIP(hipMemsetAsync(g->fc_w, 0, nf * 4, st));    THIP(hipMemsetAsync(g->fc_b, 0, cout * 4, st));
+  THIP(hipMemsetAsync(g->skip_w, 0, ns * 4, st));  THIP(hipMemsetAsync(g->skip_b, 0, cout * 4, st));
+  // out = FiLM3(fc(h2)) + conv_skip(x): both branches see dout
+  THIP(launch_film_bwd(dos, nullptr, u3, film, cols, go[2], B, L, cout, 0, du3, dfilm, cols, go[2], bo[2], st));
+  THIP(launch_wgrad(du3, h2, B, L, cout, cout, 1, g->fc_w, st));
+  THIP(launch_colsum(du3, rows, cout, g->fc_b, st));
+  if ((rc = conv_gemm(du3, B, L, cout, 1, wdf, zb, cout, dh2, st))) return rc;
+  // h2 = SiLU(FiLM2(conv2(h1)))
+  THIP(launch_film_bwd(dh2, a2, u2, film, cols, go[1], B, L, cout, 1, du2, dfilm, cols, go[1], bo[1], st));
+  THIP(launch_wgrad(du2, h1, B, L, cout, c1, 3, g->conv2_w, st));
+  THIP(launch_colsum(du2, rows, cout, g->conv2_b, st));
+  if ((rc = conv_gemm(du2, B, L, cout, 3, wd2, zb, c1, dh1, st))) return rc;
+  // h1 = SiLU(FiLM1(conv1(SiLU(x))))
+  THIP(launch_film_bwd(dh1, a1, u1, film, cols, go[0], B, L, c1, 1, du1, dfilm, cols, go[0], bo[0], st));
+  THIP(launch_wgrad(du1, sx, B, L, c1, cin, 3, g->conv1_w, st));
+  THIP(launch_colsum(du1, rows, c1, g->conv1_b, st));
+  if ((rc = conv_gemm(du1, B, L, c1, 3, wd1, zb, cin, dsx, st))) return rc;
+  // skip branch, then dx = conv_skip^T(dout) + conv1^T(..) * SiLU'(x)
+  THIP(launch_wgrad(dos, xs, B, L, cout, cin, 3, g->skip_w, st));
+  THIP(launch_colsum(dos, rows, cout, g->skip_b, st));
+  if ((rc = conv_gemm(dos, B, L, cout, 3, wds, zb, cin, dxs, st))) return rc;
+  THIP(launch_silu_bwd_add(dsx, xs, rows * cin, dxs, st));
+  THIP(hipMemcpyAsync(dx, dxs, rows * cin * 4, hipMemcpyDeviceToDevice, st));
+  // the six FiLM Linears
+  THIP(launch_film_linear_bwd(dfilm, sigma, wcat, B, cols, g->film_w, g->film_b, dsigma, st));
+  THIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// train.hip — first kernels of the training step (reference train.py:26-67): the forward-diffusion
+// perturbation, the loss and its gradient, gradient-norm clipping + Adam over flat parameter buffers, and the backward
+// pieces of a ConvBlock (cnn.py:64-87) that are not plain GEMMs — FiLM / SiLU backward with its per-sample reductions,
+// the weight-gradient contraction over stroke rows on the exact-f32 MFMA, bias gradients, the FiLM Linear backward.
+// fp32 throughout (the gradients are checked against the reference's autograd at fp32 tolerances); the data-gradient
+// convolutions run on the generic GEMM kernel with transposed / tap-flipped packed weights (dhw_train_api.cpp).
+#include "dhw_common.h"
+#include "dhw_kernels.h"
+
+namespace {
+
+DHW_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+DHW_DEV float dsilu_f(float x) { const float s = sigmoid_f(x); return s * (1.0f + x * (1.0f - s)); }
+
+// x_perturbed = sqrt(abar) x + sqrt(1 - abar) eps (train.py:41-43); alphas [B], x / eps [B, L, 2]
+__global__ __launch_bounds__(256) void perturb_kernel(const float* x, const float* eps, const float* alphas, long n, int per_sample, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float a = alphas[i / per_sample];
+  out[i] = sqrtf(a) * x[i] + sqrtf(1.0f - a) * eps[i];
+}
+
+// loss.py:5-37: score = mean_{b,l} sum_c (eps - pred)^2;  pen = mean_b( mean_l BCE(pen_pred, clamp(pen, 1e-7, 1-1e-7)) * abar_b ).
+// One block per sample accumulates its two partial sums into out[1], out[2] (fp32 atomics, B adds each) and writes the
+// gradients d loss / d pred [B,L,2], d loss / d pen_pred [B,L].  out[0] = out[1] + out[2] is formed by loss_finish.
+__global__ __launch_bounds__(256) void loss_kernel(const float* eps, const float* pred, const float* pen, const float* pen_pred,
+                                                    const float* alphas, int B, int L, float* out, float* d_pred, float* d_pen) {
+  const int b = blockIdx.x;
+  const float a = alphas[b];
+  const float inv_bl = 1.0f / ((float)B * (float)L);
+  float s = 0.f, q = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const long r = (long)b * L + l;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float d = eps[r * 2 + c] - pred[r * 2 + c];
+      s += d * d;
+      if (d_pred) d_pred[r * 2 + c] = -2.0f * d * inv_bl;
+    }
+    const float y = fminf(fmaxf(pen[r], 1e-7f), 1.0f - 1e-7f), pp = pen_pred[r];
+    // torch's binary_cross_entropy clamps the logs at -100
+    const float lp = fmaxf(logf(pp), -100.0f), lq = fmaxf(logf(1.0f - pp), -100.0f);
+    q += -(y * lp + (1.0f - y) * lq);
+    if (d_pen) d_pen[r] = (pp - y) / fmaxf(pp * (1.0f - pp), 1e-12f) * a * inv_bl;
+  }
+  __shared__ float rs[8], rq[8];
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 1, (rs[0] + rs[1] + rs[2] + rs[3]) * inv_bl);
+    atomicAdd(out + 2, (rq[0] + rq[1] + rq[2] + rq[3]) * a * inv_bl);
+  }
+}
+__global__ void loss_finish_kernel(float* out) { out[0] = out[1] + out[2]; }
+
+// sum of squares of a flat buffer -> *out (atomic), for the global gradient norm (clip_grad.py:42-43, torch clip_grad_norm_)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, float* out) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  __shared__ float r[4];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, r[0] + r[1] + r[2] + r[3]);
+}
+
+// torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected moments) on a flat buffer, with the
+// clip_grad_norm_ factor min(1, max_norm / (||g|| + 1e-6)) read from the device (sqnorm holds ||g||^2).
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2, const float* sqnorm, float max_norm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float clip = 1.0f;
+  if (sqnorm) clip = fminf(1.0f, max_norm / (sqrtf(*sqnorm) + 1e-6f));
+  const float gi = g[i] * clip + wd * p[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+// a = u * gamma[b] + beta[b];  h = SiLU(a)   (rows C-last [B*L, C]; gamma/beta [B][cols] at column offset)
+__global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* u, const float* film, long film_bs, int goff, int boff, int L, int C,
+                                                             long n4, float* a_out, float* h_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long e = i * 4, r = e / C;
+  const int c = (int)(e - r * C), b = (int)(r / L);
+  const f32x4 x = *reinterpret_cast<const f32x4*>(u + e);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(film + b * film_bs + goff + c), be = *reinterpret_cast<const f32x4*>(film + b * film_bs + boff + c);
+  f32x4 a = x * ga + be, h;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = silu_f(a[k]);
+  *reinterpret_cast<f32x4*>(a_out + e) = a;
+  if (h_out) *reinterpret_cast<f32x4*>(h_out + e) = h;
+}
+
+// Backward of a = u gamma + beta (and, with act, of h = SiLU(a)): given d = dL/dh (or dL/da), writes dL/du = d' gamma and
+// accumulates dgamma[b][c] = sum_l d' u, dbeta[b][c] = sum_l d'  (d' = d * SiLU'(a) with act).  One thread per (b, c):
+// lanes run along the contiguous channel axis, the loop over the sample's L rows is sequential (deterministic).
+__global__ __launch_bounds__(64) void film_bwd_kernel(const float* d, const float* a, const float* u, const float* film, long film_bs, int goff,
+                                                       int L, int C, int act, float* du, float* dfilm, long dfilm_bs, int dgoff, int dboff) {
+  const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  const float ga = film[b * film_bs + goff + c];
+  float sg = 0.f, sb = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const long e = ((long)b * L + l) * C + c;
+    float dd = d[e];
+    if (act) dd *= dsilu_f(a[e]);
+    sg += dd * u[e];
+    sb += dd;
+    du[e] = dd * ga;
+  }
+  dfilm[b * dfilm_bs + dgoff + c] = sg;
+  dfilm[b * dfilm_bs + dboff + c] = sb;
+}
+
+// dx += d_sx * SiLU'(x)   (the conv1 branch reads SiLU(x); the skip branch's dx is already in dx)
+__global__ __launch_bounds__(256) void silu_bwd_add_kernel(const float* d_sx, const float* x, long n, float* dx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx[i] += d_sx[i] * dsilu_f(x[i]);
+}
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const float* x, long n, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = silu_f(x[i]);
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, long n, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+// db[c] = sum over all rows of dy[r][c]: block = 64 channels x a chunk of rows, one atomic per (block, channel)
+__global__ __launch_bounds__(64) void colsum_kernel(const float* dy, long rows, int C, int rows_per_block, float* db) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += dy[r * C + c];
+  atomicAdd(db + c, s);
+}
+
+// Weight gradient of Conv1d(k = taps, 'same' zero padding inside each sample) / Linear (taps = 1), torch layout:
+//   dW[co][ci][tap] += sum_{b,l} dY[b,l,co] * X[b, l + tap - taps/2, ci]
+// a [Cout x Cin] contraction over the B*L stroke rows per tap, on the exact-f32 MFMA (16x16x4 f32: bitwise an fmaf chain).
+// One wave = one 16 x 16 (co, ci) tile of one tap over a 256-row chunk; lane (i = lane & 15, g = lane >> 4) feeds
+// dY[row 8g + j][co0 + i] as the A operand and X[row 8g + j + shift][ci0 + i] as the B operand (16 lanes read 64
+// contiguous bytes of a row).  Chunks accumulate with fp32 atomics (<= rows / 256 adds per element).
+__global__ __launch_bounds__(64) void wgrad_kernel(const float* dy, const float* x, int B, int L, int Cout, int Cin, int taps, float* dw) {
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int ci_tiles = Cin / 16;
+  int t = blockIdx.x;
+  const int tap = t % taps; t /= taps;
+  const int ci0 = (t % ci_tiles) * 16, co0 = (t / ci_tiles) * 16;
+  const long rows = (long)B * L, r_begin = (long)blockIdx.y * 256;
+  const int shift = tap - taps / 2;
+  f32x4 acc = (f32x4){0, 0, 0, 0};
+  for (int s = 0; s < 8; ++s) {
+    Frag<float> fa, fb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long r = r_begin + s * 32 + 8 * g + j;
+      float va = 0.f, vb = 0.f;
+      if (r < rows) {
+        va = dy[r * Cout + co0 + i];
+        const int l = (int)(r % L) + shift;
+        if (l >= 0 && l < L) vb = x[(r + shift) * Cin + ci0 + i];
+      }
+      if (j < 4) { fa.lo[j] = va; fb.lo[j] = vb; } else { fa.hi[j - 4] = va; fb.hi[j - 4] = vb; }
+    }
+    mma32(acc, fa, fb);
+  }
+  // acc[r] = dW tile[co = 4g + r][ci = i]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) atomicAdd(dw + ((size_t)(co0 + 4 * g + r) * Cin + ci0 + i) * taps + tap, acc[r]);
+}
+
+// FiLM Linears (conditioning.py:16-18): film[b][c] = Wcat[c][:] . sigma[b] + bcat[c].  Backward, all of a block's 6 Linears:
+// dW[c][k] = sum_b dfilm[b][c] sigma[b][k], db[c] = sum_b dfilm[b][c], dsigma[b][k] = sum_c dfilm[b][c] W[c][k].
+__global__ __launch_bounds__(256) void film_linear_bwd_kernel(const float* dfilm, const float* sigma, const float* wcat, int B, int cols,
+                                                               float* dw, float* db, float* dsigma) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < cols * 32) {
+    const int c = idx / 32, k = idx % 32;
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) { s += dfilm[(long)b * cols + c] * sigma[b * 32 + k]; sb += dfilm[(long)b * cols + c]; }
+    dw[idx] = s;
+    if (k == 0) db[c] = sb;
+  }
+  if (idx < B * 32) {
+    const int b = idx / 32, k = idx % 32;
+    float s = 0.f;
+    for (int c = 0; c < cols; ++c) s += dfilm[(long)b * cols + c] * wcat[c * 32 + k];
+    dsigma[idx] = s;
+  }
+}
+
+inline unsigned nb(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t launch_perturb(const float* x, const float* eps, const float* alphas, int B, int L, float* out, hipStream_t st) {
+  const long n = (long)B * L * 2;
+  hipLaunchKernelGGL(perturb_kernel, dim3(nb(n)), dim3(256), 0, st, x, eps, alphas, n, L * 2, out);
+  return hipGetLastError();
+}
+hipError_t launch_loss(const float* eps, const float* pred, const float* pen, const float* pen_pred, const float* alphas, int B, int L,
+                       float* out3, float* d_pred, float* d_pen, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out3, 0, 3 * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, st, eps, pred, pen, pen_pred, alphas, B, L, out3, d_pred, d_pen);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, out3);
+  return hipGetLastError();
+}
+hipError_t launch_sqnorm(const float* g, long n, float* out, hipStream_t st) {   // out must be zeroed by the caller (several buffers add up)
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(std::min<unsigned>(nb(n), 1024u)), dim3(256), 0, st, g, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                       const float* sqnorm, float max_norm, hipStream_t st) {
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nb(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, sqnorm, max_norm);
+  return hipGetLastError();
+}
+hipError_t launch_film_silu_fwd(const float* u, const float* film, long film_bs, int goff, int boff, int B, int L, int C, float* a, float* h, hipStream_t st) {
+  const long n4 = (long)B * L * C / 4;
+  hipLaunchKernelGGL(film_silu_fwd_kernel, dim3(nb(n4)), dim3(256), 0, st, u, film, film_bs, goff, boff, L, C, n4, a, h);
+  return hipGetLastError();
+}
+hipError_t launch_film_bwd(const float* d, const float* a, const float* u, const float* film, long film_bs, int goff, int B, int L, int C, int act,
+                           float* du, float* dfilm, long dfilm_bs, int dgoff, int dboff, hipStream_t st) {
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(nb(C, 64), B), dim3(64), 0, st, d, a, u, film, film_bs, goff, L, C, act, du, dfilm, dfilm_bs, dgoff, dboff);
+  return hipGetLastError();
+}
+hipError_t launch_silu_bwd_add(const float* d_sx, const float* x, long n, float* dx, hipStream_t st) {
+  hipLaunchKernelGGL(silu_bwd_add_kernel, dim3(nb(n)), dim3(256), 0, st, d_sx, x, n, dx);
+  return hipGetLastError();
+}
+hipError_t launch_silu_fwd(const float* x, long n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(nb(n)), dim3(256), 0, st, x, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_add(const float* a, const float* b, long n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(add_kernel, dim3(nb(n)), dim3(256), 0, st, a, b, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_colsum(const float* dy, long rows, int C, float* db, hipStream_t st) {   // db zeroed by the caller
+  const int rpb = 512;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb(C, 64), nb(rows, rpb)), dim3(64), 0, st, dy, rows, C, rpb, db);
+  return hipGetLastError();
+}
+hipError_t launch_wgrad(const float* dy, const float* x, int B, int L, int Cout, int Cin, int taps, float* dw, hipStream_t st) {   // dw zeroed by the caller
+  if (Cout % 16 || Cin % 16 || (taps != 1 && taps != 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((Cout / 16) * (Cin / 16) * taps, nb((long)B * L, 256)), dim3(64), 0, st, dy, x, B, L, Cout, Cin, taps, dw);
+  return hipGetLastError();
+}
+hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const float* wcat, int B, int cols, float* dw, float* db, float* dsigma, hipStream_t st) {
+  hipLaunchKernelGGL(film_linear_bwd_kernel, dim3(nb(std::max((long)cols * 32, (long)B * 32))), dim3(256), 0, st, dfilm, sigma, wcat, B, cols, dw, db, dsigma);
+  return hipGetLastError();
+}

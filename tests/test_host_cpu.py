@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     syms = set()
-    for h in ("dhw.h", "dhw_debug.h", "dhw_style.h"):
+    for h in ("dhw.h", "dhw_debug.h", "dhw_style.h", "dhw_train.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         syms |= set(re.findall(r"\b(dhw_[a-z0-9_]+)\s*\(", src))
