@@ -18,7 +18,7 @@ def main():
     d, out = sys.argv[1:3]
     tot = defaultdict(lambda: defaultdict(float))
     n = defaultdict(int)
-    for path in glob.glob(os.path.join(d, "*counter_collection.csv")):
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 k = base(row["Kernel_Name"])

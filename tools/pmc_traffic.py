@@ -47,9 +47,11 @@ def main():
         write = wt.get(k, 0.0) * 1024 / max(wc.get(k, 0), 1)
         kernels[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                       "hbm_bytes_per_launch": fetch + write}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash   # the csrc/ hash these passes were taken at: bench.py marks the figure stale when it differs
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 1 "
-                         "--no-cpu-baseline`; KiB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md (HBM section)",
-               "kernels": kernels}, open(out, "w"), indent=1)
+                         "--no-cpu-baseline --no-kernel-profile --no-fp32`; KiB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md (HBM section)",
+               "kernel_source_hash": kernel_source_hash(), "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:32s} launches {v['launches']:5d}  fetch {v['fetch_bytes_per_launch']/1e6:8.2f} MB  write {v['write_bytes_per_launch']/1e6:8.2f} MB")
 
