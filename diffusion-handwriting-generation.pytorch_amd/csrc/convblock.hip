@@ -27,10 +27,7 @@ namespace {
 #define CB_SILU(x) ((DHW_ABL & 8) ? (x) : silu_t<T>(x))
 #define CB_BARRIER() do { if constexpr (!(DHW_ABL & 64)) lds_barrier(); } while (0)
 
-#define STAMP(slot)                                                                                   \
-  do {                                                                                                \
-    if (p.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) p.stamps[(threadIdx.x >> 6) * 16 + slot] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
+#define STAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0, (threadIdx.x >> 6) * 16 + slot, __builtin_amdgcn_s_memrealtime())
 
 // Row stride of the h2 / output staging tile: the conflict-free operand padding, except for the 126-row tiles, where the
 // decoder block with the fused input stage would overflow LDS by 2 KB (128 channels with the 16-byte padding: one
@@ -40,12 +37,23 @@ template <typename T, int BM> __host__ __device__ constexpr int h2_stride(int CO
 template <int NT>
 struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles, requested before the main loop
   f32x4 bias[NT], gam[NT], bet[NT];
-  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {
+  // Two forms, chosen at the call site: a run-time `g ? load : 1` turns into a branch whose merge copies the loaded value
+  // at once — hipcc then waits s_waitcnt vmcnt(0) right behind the weight prefetch the caller has just issued, i.e. it
+  // drains the whole queue once per stage (found in the .s of every fused kernel, r2).
+  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {   // bias + FiLM gamma / beta (all non-null)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
-      gam[i] = g ? *reinterpret_cast<const f32x4*>(g + n0 + 16 * i) : (f32x4){1, 1, 1, 1};
-      bet[i] = be ? *reinterpret_cast<const f32x4*>(be + n0 + 16 * i) : (f32x4){0, 0, 0, 0};
+      gam[i] = *reinterpret_cast<const f32x4*>(g + n0 + 16 * i);
+      bet[i] = *reinterpret_cast<const f32x4*>(be + n0 + 16 * i);
+    }
+  }
+  DHW_DEV void load_bias(const float* b, int n0) {   // bias only (gamma = 1, beta = 0)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+      gam[i] = (f32x4){1, 1, 1, 1};
+      bet[i] = (f32x4){0, 0, 0, 0};
     }
   }
 };
@@ -162,7 +170,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     if (actu) {   // (requested behind the staging loads: see below)
       if constexpr (SK) ringu.template fill_s<3 * UCH / 32>(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8);
       else ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
-      epu.load(p.up_b, nullptr, nullptr, nu);
+      epu.load_bias(p.up_b, nu);
     }
     CB_BARRIER();
     STAMP(10);
@@ -326,7 +334,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     for (int i = 0; i < NT2; ++i)
 #pragma unroll
       for (int j = 0; j < MT2; ++j) acc[i][j] = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
-    ep2.load(p.b_skip, nullptr, nullptr, n2);
+    ep2.load_bias(p.b_skip, n2);
     if constexpr (SK) ring2.template run_s<MT2, KT1>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);   // out row i <- x rows i+1+tap
     else ring2.template run<MT2>(acc, XR + (row02 + l15 + 1) * SX + g * 8 * ES, SX, KCin);
   }

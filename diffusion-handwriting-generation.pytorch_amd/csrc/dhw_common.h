@@ -19,6 +19,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DHW_DEV __device__ __forceinline__
 
+// Diagnostic per-stage time stamps (s_memrealtime -> p.stamps[slot]) exist only in builds with -DDHW_STAMPS (the
+// micro-benchmarks under tools/).  Even behind a run-time `if (p.stamps ...)` the stamp blocks changed the product's code:
+// each is a conditional region with a global store, and hipcc's s_waitcnt bookkeeping at the region's join point waited
+// for the weight prefetch issued just before (s_waitcnt vmcnt(0..2) instead of a counted vmcnt(17)).
+#ifdef DHW_STAMPS
+#define DHW_STAMP_IF(cond, slot_expr, value) do { if (cond) p.stamps[slot_expr] = (value); } while (0)
+#else
+#define DHW_STAMP_IF(cond, slot_expr, value) do { } while (0)
+#endif
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { f32x4 lo, hi; };

@@ -9,10 +9,7 @@
 #include "dhw_kernels.h"
 
 // diagnostic stage stamps (100 MHz s_memrealtime), only when the caller passes a buffer
-#define ENC_STAMP(slot)                                                                                   \
-  do {                                                                                                \
-    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
+#define ENC_STAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, slot, __builtin_amdgcn_s_memrealtime())
 
 template <typename T, int BM>
 DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
@@ -43,12 +40,23 @@ DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int
 template <int NT>
 struct EpiParams {
   f32x4 bias[NT], gam[NT], bet[NT];
-  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {   // n0: first channel of this lane
+  // Two forms, chosen at the call site: a run-time `g ? load : 1` turns into a branch whose merge copies the loaded value
+  // at once — hipcc then waits s_waitcnt vmcnt(0) right behind the weight prefetch the caller has just issued, i.e. it
+  // drains the whole queue once per stage (found in the .s of every fused kernel, r2).
+  DHW_DEV void load(const float* b, const float* g, const float* be, int n0) {   // bias + FiLM gamma / beta (all non-null)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
-      gam[i] = g ? *reinterpret_cast<const f32x4*>(g + n0 + 16 * i) : (f32x4){1, 1, 1, 1};
-      bet[i] = be ? *reinterpret_cast<const f32x4*>(be + n0 + 16 * i) : (f32x4){0, 0, 0, 0};
+      gam[i] = *reinterpret_cast<const f32x4*>(g + n0 + 16 * i);
+      bet[i] = *reinterpret_cast<const f32x4*>(be + n0 + 16 * i);
+    }
+  }
+  DHW_DEV void load_bias(const float* b, int n0) {   // bias only (gamma = 1, beta = 0)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+      gam[i] = (f32x4){1, 1, 1, 1};
+      bet[i] = (f32x4){0, 0, 0, 0};
     }
   }
 };
@@ -132,7 +140,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane);
-    ep.load(p.b_q1, nullptr, nullptr, n0);
+    ep.load_bias(p.b_q1, n0);
   }
   lds_barrier();
   ENC_STAMP(1);
@@ -254,7 +262,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     acc_zero(acc);
     f32x4 pb[NT][MT];
     if (act) {
-      ep.load(p.b_qkv2 + chunk * DM, nullptr, nullptr, n0 + opaque);
+      ep.load_bias(p.b_qkv2 + chunk * DM, n0 + opaque);
       if (chunk < 2) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   WRing<T, NT, RING> ring;
   EpiParams<NT> ep;
   STAMP(16);
-  if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[40] = __builtin_amdgcn_s_memtime();
+  DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 40, __builtin_amdgcn_s_memtime());
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
     constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + 16;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (act) {
       f32x4 acc[NT][MT];
       acc_zero(acc);
-      ep.load(p.b_f1 + hh * DM, nullptr, nullptr, n0);
+      ep.load_bias(p.b_f1 + hh * DM, n0);
       ring.template run_s<MT, KC>(acc, op1, S, KC);
       // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.pool)
     tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);
-  if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[41] = __builtin_amdgcn_s_memtime();
+  DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 41, __builtin_amdgcn_s_memtime());
 
   if constexpr (NEXT == 1) {
     // the next layer's enc_a on the out tile (R3): q1 / a1 in R1, the v2 staging area over R1..R2 (both dead by now)
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     EpiParams<NTN> epd;
     const int nt0 = wave * NTN, nn0 = nt0 * 16 + 4 * g;
     rd.template fill_s<KC>(reinterpret_cast<const T*>(nx.w_dense) + ((size_t)nt0 * KC * 64 + lane) * 8);
-    epd.load(nx.b_dense, nullptr, nullptr, nn0);
+    epd.load_bias(nx.b_dense, nn0);
     lds_barrier();   // pooled tile complete; every read of the out tile (copy-out, pooling) is done
     char* XN = R2;   // x tile of the chained layer, then its q1 tile: together BM * SN <= 2 * BM * S bytes over R2..R3
     {

@@ -27,10 +27,7 @@
 
 namespace {
 
-#define GSTAMP(slot)                                                                                               \
-  do {                                                                                                             \
-    if (p.stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
+#define GSTAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0, slot, __builtin_amdgcn_s_memrealtime())
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   stage_film_384<T, 8>(RS, S, sty, p.S5, SM, gam + p.f1, bet + p.f1, tid);
   stage_film_384<T, 4>(RT, S, tn, p.Lt, BM, gam + p.f2, bet + p.f2, tid);
   ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_kv8) + (size_t)DM * DM + wlane);   // V half of the stacked K|V projection
-  ep.load(p.b_kv8 + DM, nullptr, nullptr, n0);
+  ep.load_bias(p.b_kv8 + DM, n0);
   lds_barrier();
 
   {  // ---- V^T = (s Wv + bv)^T, keys contiguous, zero past the style rows
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) *reinterpret_cast<T*>(RV + (n0 + 16 * i + k) * SVT + key * ES) = from_f<T>(key < p.S5 ? v[k] : 0.f);
       }
-    ep.load(p.b_kv8, nullptr, nullptr, n0);
+    ep.load_bias(p.b_kv8, n0);
   }
   {  // ---- K = s Wk + bk, written over s once every wave has finished reading it
     f32x4 acc[NT][MTS];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MTS; ++j) store4(reinterpret_cast<T*>(RS + (j * 16 + l15) * S) + n0 + 16 * i, acc[i][j] + ep.bias[i]);
-    ep.load(p.b_q8, nullptr, nullptr, n0);
+    ep.load_bias(p.b_q8, n0);
   }
   {  // ---- q = t1 Wq + bq, in place
     f32x4 acc[NT][MT];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   FilmRow<NT> f2r, f3r;
   f2r.load(gam + p.f2, bet + p.f2, n0);
   f3r.load(gam + p.f3, bet + p.f3, n0);
-  ep.load(p.b_d8, nullptr, nullptr, n0);
+  ep.load_bias(p.b_d8, n0);
   lds_barrier();
 
   // ---- m = MHA8(q, K, V): wave = one head, both 16-row query groups; the output replaces q in place (a wave reads and
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int hh = 0; hh < 2; ++hh) {
     f32x4 acc[NT][MT];
     acc_zero(acc);
-    ep.load(p.b_tf1 + hh * DM, nullptr, nullptr, n0);
+    ep.load_bias(p.b_tf1 + hh * DM, n0);
     ring.template run_s<MT, KC>(acc, s2op, S, KC);
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_tf3) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
     f32x4 acc[NT][MT];
     acc_zero(acc);
     if (act) {
-      ep.load(p.b_kv, nullptr, nullptr, n0);
+      ep.load_bias(p.b_kv, n0);
       ring.template run_s<MT, KCO>(acc, lop, SO, KCO);
       ring.template fill_s<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)(DMO / 16 + ntile0) * KCO * 64 + lane) * 8);   // V half
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
     f32x4 acc[NT][MT];
     acc_zero(acc);
     if (act) {
-      ep.load(p.b_kv + DMO, nullptr, nullptr, n0);
+      ep.load_bias(p.b_kv + DMO, n0);
       ring.template run_s<MT, KCO>(acc, lop, SO, KCO);
     }
     lds_barrier();   // the k1 copy-out has read the staging tile
