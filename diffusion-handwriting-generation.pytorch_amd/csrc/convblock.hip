@@ -117,7 +117,10 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   const float* bet = gam + p.film_tot;
 
   // wave coordinates of the two layouts
-  const bool act1 = wave < WM1 * WN1, act2 = wave < WM2 * WN2;   // idle waves only join the barriers / copies
+  // idle waves only join the barriers / copies.  When a layout uses all NW waves the flag must FOLD to true: a run-time
+  // `if (act)` around a stage whose loads are consumed inside it leaves, on the (never taken) skip path, loads that were
+  // never waited for, and hipcc's s_waitcnt merge at the join then drains the next stage's weight prefetch (r2, .s).
+  const bool act1 = WM1 * WN1 == NW || wave < WM1 * WN1, act2 = WM2 * WN2 == NW || wave < WM2 * WN2;
   const int wm1 = act1 ? wave / WN1 : 0, wn1 = act1 ? wave % WN1 : 0, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
   const int wm2 = act2 ? wave / WN2 : 0, wn2 = act2 ? wave % WN2 : 0, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
@@ -147,7 +150,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     constexpr int RXP = (RX + 15) / 16 * 16, RH = RXP + 2, MTU = RXP / 16;
     constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 4, NTU = TU / WNU;   // (12 tiles: 4 waves, one per SIMD, 3 tiles each)
     static_assert(NTU * WNU == TU && NW == 8, "unsupported input width");
-    const bool actu = wave < WNU;
+    const bool actu = WNU == NW || wave < WNU;
     const int ntu0 = (actu ? wave : 0) * NTU, nu = ntu0 * 16 + 4 * g;
     constexpr int UCH = up_skip_width<UPC>();
     const int Ch = SK ? UCH : p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);

@@ -103,8 +103,15 @@ struct WRing {
     base = wbase;
     KT = KT_;
     KTS = kts ? kts : KT_;
+    // issue order = consumption order: hipcc's scheduler otherwise clusters the prefetch loads by address and may issue the
+    // first-needed fragment LAST (loads return in order: the stage's first MFMA then waits for the whole prefetch)
 #pragma unroll
-    for (int d = 0; d < (D < KT_ ? D : KT_); ++d) load_chunk(d, d);
+    for (int d = 0; d < (D < KT_ ? D : KT_); ++d) {
+      load_chunk(d, d);
+#ifdef DHW_ORDERED_FILL
+      asm volatile("" ::: "memory");
+#endif
+    }
   }
   template <int MT, int KT_, int ABL = DHW_ABL>
   DHW_DEV void run_s(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
