@@ -190,14 +190,22 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
 template <int KB>
 struct PadMask {
   int64_t tok[KB / 4];
+  // Unconditional loads at a clamped index: a per-lane `key < Lk ? trow[key] : 1` compiles to one branch per token with
+  // s_waitcnt vmcnt(0) inside — eight dependent memory round trips at the top of every enc_a (r2, .s) — while keys at or
+  // past Lk are masked by attn_block_lds itself, so their bits may hold anything.
   DHW_DEV void load(const int64_t* trow, int kb, int Lk) {
     const int g = (threadIdx.x & 63) >> 4;
+    if (!trow) {   // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < KB / 4; ++i) tok[i] = 1;
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < KB / 16; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kb + 16 * t + 4 * g + r;
-        tok[4 * t + r] = (trow && key < Lk) ? trow[key] : 1;
+        tok[4 * t + r] = trow[key < Lk ? key : Lk - 1];
       }
   }
   DHW_DEV unsigned bits() const {

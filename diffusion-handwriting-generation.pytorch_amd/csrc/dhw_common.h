@@ -138,24 +138,26 @@ DHW_DEV void staged_copy(int total, int tid, int nthreads, SrcF src, DstF dst) {
 template <int U>
 struct CopyRegs {
   uint4 v[U];
+  // src(id) must return a VALID address for every id < total (clamp the row instead of returning null): a conditional
+  // per-lane load compiles to a branch with s_waitcnt vmcnt(0) at its join, which serialises the tiles again.  Pieces that
+  // must read as zero are cleared by store() (keep(id) == false), with a select instead of a branch.
   template <typename SrcF>
   DHW_DEV void load(int total, int tid, int nthreads, SrcF src) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int id = tid + u * nthreads;
-      v[u] = make_uint4(0, 0, 0, 0);
-      if (id < total) {
-        const uint4* sp = src(id);
-        if (sp) v[u] = *sp;
-      }
+      v[u] = *src(id < total ? id : total - 1);
     }
   }
-  template <typename DstF>
-  DHW_DEV void store(int total, int tid, int nthreads, DstF dst) {
+  template <typename DstF, typename KeepF>
+  DHW_DEV void store(int total, int tid, int nthreads, DstF dst, KeepF keep) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int id = tid + u * nthreads;
-      if (id < total) *dst(id) = v[u];
+      if (id < total) {
+        const bool k = keep(id);
+        *dst(id) = make_uint4(k ? v[u].x : 0u, k ? v[u].y : 0u, k ? v[u].z : 0u, k ? v[u].w : 0u);
+      }
     }
   }
 };

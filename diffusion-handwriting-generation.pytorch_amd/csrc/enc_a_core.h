@@ -123,15 +123,18 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     const T* xs = reinterpret_cast<const T*>(p.x);
     if (p.x)
       cx.load(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
-                                                return m0 + r < p.Lk ? reinterpret_cast<const uint4*>(xs + (size_t)(b * p.Lk + m0 + r) * DM + cc * EPV) : nullptr; });
+                                                return reinterpret_cast<const uint4*>(xs + (size_t)(b * p.Lk + (m0 + r < p.Lk ? m0 + r : p.Lk - 1)) * DM + cc * EPV); });
     ck.load(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
-                                               return r < p.Lt ? reinterpret_cast<const uint4*>(k1s + (size_t)r * DM + cc * EPV) : nullptr; });
+                                               return reinterpret_cast<const uint4*>(k1s + (size_t)(r < p.Lt ? r : p.Lt - 1) * DM + cc * EPV); });
     cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
-                                              return (part + 1) * EPV <= p.lpadT ? reinterpret_cast<const uint4*>(v1s + (size_t)ch * p.lpadT + part * EPV) : nullptr; });
+                                              return reinterpret_cast<const uint4*>(v1s + (size_t)ch * p.lpadT + ((part + 1) * EPV <= p.lpadT ? part * EPV : 0)); });
     if (p.x)
-      cx.store(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(XR + r * S + cc * 16); });
-    ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); });
-    cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SVC + part * 16); });
+      cx.store(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(XR + r * S + cc * 16); },
+               [&](int id) { return m0 + id / CPR < p.Lk; });
+    ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); },
+             [&](int id) { return id / CPR < p.Lt; });
+    cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SVC + part * 16); },
+             [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
   }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
   PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1

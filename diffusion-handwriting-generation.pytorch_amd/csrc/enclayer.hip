@@ -165,9 +165,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+          // unconditional (rows past the sample read the next sample / the buffer's slack rows and are never written
+          // back): a per-lane `r < Lk ? load : 0` compiles to a branch with s_waitcnt vmcnt(0) inside, which drains the
+          // weight prefetch issued in front of the barrier — once per row tile
           const int r = m0 + row0 + j * 16 + l15;
-          res[i][j] = r < p.Lk ? load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i))
-                               : (f32x4){0, 0, 0, 0};
+          res[i][j] = load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i));
         }
       ring.template run_s<MT, KC>(acc, op1, S, KC);
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue

@@ -237,11 +237,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int r = j * 16 + l15;
-        f32x4 res = (f32x4){0, 0, 0, 0};
-        if (r < p.Lt) {   // t1 again (it was overwritten by q): the same rounding as the staged copy
+        // t1 again (it was overwritten by q), with the rounding of the staged copy.  Unconditional load (rows past Lt read
+        // the next prompt's / the slack rows; those output rows are never written): a per-lane `if (r < Lt) load` becomes
+        // a branch with s_waitcnt vmcnt(0) inside and drains the weight prefetch
+        f32x4 res;
+        {
           const f32x4 x = load4(tn + (size_t)r * DM + n0 + 16 * i);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) res[k] = to_f(from_f<T>(x[k] * f2r.gam[i][k] + f2r.bet[i][k]));
+          for (int k = 0; k < 4; ++k) res[k] = r < p.Lt ? to_f(from_f<T>(x[k] * f2r.gam[i][k] + f2r.bet[i][k])) : 0.f;
         }
         acc[i][j] += ep.bias[i] + res;
       }
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
         for (int j = 0; j < MT; ++j) {
           const int r = j * 16 + l15;
           f32x4 v = acc[i][j] + ep.bias[i];
-          if (r < p.Lt) v += *reinterpret_cast<const f32x4*>(p.pb_k1 + (size_t)r * DMO + n0 + 16 * i);
+          v += *reinterpret_cast<const f32x4*>(p.pb_k1 + (size_t)(r < p.Lt ? r : p.Lt - 1) * DMO + n0 + 16 * i);   // (clamped, not branched)
           store4(reinterpret_cast<T*>(XS + r * SO) + n0 + 16 * i, v);   // (the SiLU(text) tile is dead: two barriers ago)
         }
     }
