@@ -55,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="concurrent prompt sub-batches per GPU (0 = library default)")
     # launcher / distributed plumbing rehearsal on CPU (tests/test_bench_launcher_cpu.py): gloo, no GPU, no library
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses GPU r %% device_count, gloo instead of RCCL "
+                         "for the barrier (RCCL refuses two ranks on one device); the line is marked, never a scaling result")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -123,14 +126,15 @@ def worker(args):
     if args.stub:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank if world > 1 else 0)
-        dev = torch.device("cuda", local_rank if world > 1 else 0)
+        di = (local_rank % max(1, torch.cuda.device_count())) if args.share_gpu else (local_rank if world > 1 else 0)
+        torch.cuda.set_device(di)
+        dev = torch.device("cuda", di)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.stub:
+        if args.stub or args.share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -192,11 +196,12 @@ def worker(args):
     dt = time.perf_counter() - t0
     per_rank = [dt_own]
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        cdev = torch.device("cpu") if (args.stub or args.share_gpu) else dev     # gloo reduces host tensors
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        own = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(own, torch.tensor([dt_own], device=dev, dtype=torch.float64))
+        own = [torch.zeros(1, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(own, torch.tensor([dt_own], device=cdev, dtype=torch.float64))
         per_rank = [float(x.item()) for x in own]
     assert out is not None and bool(torch.isfinite(out).all()), "non-finite samples"
 
@@ -223,6 +228,8 @@ def worker(args):
     }
     if args.stub:
         res["data"] = "stub (launcher rehearsal, no GPU work)"
+    if args.share_gpu:
+        res["data"] = "synthetic; REHEARSAL: ranks share GPUs (not a scaling measurement)"
 
     if rank == 0:
         print(f"[bench] {value:.4g} stroke-points/s, {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)

@@ -445,7 +445,7 @@ hipError_t convblock_init() {
   hipError_t e;
 #define A(...) if ((e = attr<__VA_ARGS__>()) != hipSuccess) return e
   // run-time input width (decoder blocks without the fused input stage, experiments)
-  A(bf16_t, 64, 128, 8); A(bf16_t, 128, 128, 8); A(bf16_t, 64, 128, 8, 2); A(bf16_t, 64, 192, 8, 2); A(bf16_t, 64, 192, 8);
+  A(bf16_t, 64, 128, 8); A(bf16_t, 128, 128, 8); A(bf16_t, 64, 128, 8, 2, 0, 0, 128); A(bf16_t, 64, 192, 8, 2, 0, 0, 128); A(bf16_t, 64, 192, 8);
   A(bf16_t, 64, 256, 8); A(bf16_t, 32, 256, 8); A(bf16_t, 48, 256, 8);
   // encoder blocks, input width compiled in
   A(bf16_t, 64, 128, 8, 1, 0, 0, 128); A(bf16_t, 128, 128, 8, 1, 0, 0, 128); A(bf16_t, 64, 192, 8, 1, 0, 0, 128);
@@ -489,14 +489,14 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
         const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
-        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
-          return launch_t<bf16_t, 64, 128, 8, 2>(p, st);
+        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && sk && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 128, 8, 2, 0, 0, 128>(p, st);
         if (sk) return big ? launch_t<bf16_t, 128, 128, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 0, 0, 128>(p, st);
         return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
       }
       case 192:
-        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
-          return launch_t<bf16_t, 64, 192, 8, 2>(p, st);
+        if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && sk && lds_bytes<bf16_t, 64, 192>(p.Cin) <= 80 * 1024)
+          return launch_t<bf16_t, 64, 192, 8, 2, 0, 0, 128>(p, st);
         return sk ? launch_t<bf16_t, 64, 192, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
         if (use_bm48(p)) return sk ? launch_t<bf16_t, 48, 256, 8, 1, 0, 0, 192>(p, st) : launch_t<bf16_t, 48, 256, 8>(p, st);
