@@ -7,4 +7,4 @@ from .vis import show_strokes, strokes_to_polylines  # noqa: F401
 from .model import DiffusionModel, DiffusionWriter  # noqa: F401
 from .style_extractor import StyleExtractor  # noqa: F401
 from .tokenizer import Tokenizer, stroke_length  # noqa: F401
-from . import train  # noqa: F401
+from . import train, train_model  # noqa: F401

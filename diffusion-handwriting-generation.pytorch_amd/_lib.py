@@ -23,6 +23,14 @@ class DhwDims(C.Structure):
                 ("precision", C.c_int)]
 
 
+class GemmDesc(C.Structure):   # include/dhw_train.h dhw_gemm_desc
+    _fields_ = [("A", C.c_void_p), ("sam", C.c_longlong), ("sak", C.c_longlong), ("sazo", C.c_longlong), ("sazi", C.c_longlong), ("a_shift", C.c_int),
+                ("B", C.c_void_p), ("sbk", C.c_longlong), ("sbn", C.c_longlong), ("sbzo", C.c_longlong), ("sbzi", C.c_longlong), ("b_shift", C.c_int),
+                ("C", C.c_void_p), ("scm", C.c_longlong), ("scn", C.c_longlong), ("sczo", C.c_longlong), ("sczi", C.c_longlong),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nzo", C.c_int), ("nzi", C.c_int), ("lr", C.c_int),
+                ("bias", C.c_void_p), ("alpha", C.c_float), ("accumulate", C.c_int)]
+
+
 class ConvBlockWeights(C.Structure):   # include/dhw_train.h dhw_convblock_weights (HOST pointers) / dhw_convblock_grads (DEVICE pointers)
     _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "fc_w", "fc_b", "skip_w", "skip_b", "film_w", "film_b")]
 
@@ -37,6 +45,7 @@ _lib = None
 
 # every symbol include/dhw.h and include/dhw_debug.h declare: (restype, argtypes)
 _P = C.c_void_p
+_LL = C.c_longlong
 SIGNATURES = {
     "dhw_create": (C.c_int, [C.POINTER(_P), C.POINTER(DhwDims), C.c_int]),
     "dhw_load": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int]),
@@ -77,6 +86,22 @@ SIGNATURES = {
     "dhw_train_convblock": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(ConvBlockWeights), _P, _P, _P,
                                       C.POINTER(ConvBlockWeights), _P]),
     "dhw_train_last_error": (C.c_char_p, []),
+    "dhw_op_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "dhw_op_unary": (C.c_int, [C.c_int, _P, _LL, _P, _P]),
+    "dhw_op_unary_bwd": (C.c_int, [C.c_int, _P, _P, _LL, _P, C.c_int, _P]),
+    "dhw_op_add": (C.c_int, [_P, _P, _LL, _P, C.c_int, _P]),
+    "dhw_op_add_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "dhw_op_film": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "dhw_op_film_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "dhw_op_layernorm": (C.c_int, [_P, _LL, C.c_int, _P, _P, _P, _P]),
+    "dhw_op_layernorm_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, _P, C.c_int, _P]),
+    "dhw_op_softmax": (C.c_int, [_P, _LL, C.c_int, _LL, _P, C.c_float, _P, _P]),
+    "dhw_op_softmax_bwd": (C.c_int, [_P, _P, _LL, C.c_int, C.c_float, _P, _P]),
+    "dhw_op_resample": (C.c_int, [C.c_int, _P, _LL, C.c_int, _P, C.c_int, _P]),
+    "dhw_op_embedding": (C.c_int, [_P, _P, _LL, C.c_int, _P, _P]),
+    "dhw_op_embedding_bwd": (C.c_int, [_P, _P, _LL, C.c_int, _P, _P]),
+    "dhw_op_mask_mul": (C.c_int, [_P, _P, C.c_float, _LL, _P, C.c_int, _P]),
+    "dhw_op_colsum": (C.c_int, [_P, _LL, C.c_int, _P, _P]),
     "dhw_debug_randn": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 

@@ -220,3 +220,27 @@ hipError_t launch_add(const float* a, const float* b, long n, float* out, hipStr
 hipError_t launch_colsum(const float* dy, long rows, int C, float* db, hipStream_t st);
 hipError_t launch_wgrad(const float* dy, const float* x, int B, int L, int Cout, int Cin, int taps, float* dw, hipStream_t st);
 hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const float* wcat, int B, int cols, float* dw, float* db, float* dsigma, hipStream_t st);
+
+// generic fp32 ops of the training step (train.hip): see include/dhw_train.h (dhw_op_*)
+struct OpGemm {
+  const float* A; long sam, sak, sazo, sazi; int a_shift;
+  const float* B; long sbk, sbn, sbzo, sbzi; int b_shift;
+  float* C; long scm, scn, sczo, sczi;
+  int M, N, K, nzo, nzi, lr;
+  const float* bias; float alpha; int accumulate;
+};
+hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
+hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st);
+hipError_t launch_unary_bwd(int kind, const float* dy, const float* x, long n, float* dx, int accumulate, hipStream_t st);
+hipError_t launch_add2(const float* a, const float* b, long n, float* out, int accumulate, hipStream_t st);
+hipError_t launch_add_rows(const float* x, const float* table, long n, long per_sample, float* out, hipStream_t st);
+hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, float* y, hipStream_t st);
+hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, long pstride, int B, int L, int C, float* du, int accumulate, float* dgam,
+                            float* dbet, hipStream_t st);
+hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st);
+hipError_t launch_ln_bwd(const float* dy, const float* y, const float* rstd, long rows, int C, float* dx, int accumulate, hipStream_t st);
+hipError_t launch_softmax_fwd(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p, hipStream_t st);
+hipError_t launch_softmax_bwd(const float* dp, const float* p, long rows, int cols, float scale, float* ds, hipStream_t st);
+hipError_t launch_pool(int mode, const float* x, long n_out, int C, float* y, int accumulate, hipStream_t st);
+hipError_t launch_embed(int bwd, const int64_t* ids, const float* src, long n, int C, float* dst, hipStream_t st);
+hipError_t launch_mask_mul(const float* x, const float* mask, float scale, long n, float* y, int accumulate, hipStream_t st);

@@ -221,4 +221,95 @@ int dhw_train_convblock(int device, int B, int L, int cin, int cout, const float
   return 0;
 }
 
+#define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
+
+int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
+  OPCHECK(d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->nzo > 0 && d->nzi > 0 && d->lr >= 0, "dhw_op_gemm");
+  if ((d->a_shift || d->b_shift) && d->lr < 1) return tfail(DHW_ERR_ARG, "dhw_op_gemm: a shift needs lr (rows per sample)");
+  OpGemm g;
+  g.A = d->A; g.sam = d->sam; g.sak = d->sak; g.sazo = d->sazo; g.sazi = d->sazi; g.a_shift = d->a_shift;
+  g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.b_shift = d->b_shift;
+  g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr;
+  g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate;
+  THIP(launch_sgemm(g, (hipStream_t)hip_stream));
+  return 0;
+}
+int dhw_op_unary(int kind, const float* x, long long n, float* y, void* st) {
+  OPCHECK(x && y && n > 0 && (kind == 0 || kind == 1), "dhw_op_unary");
+  THIP(launch_unary(kind, x, n, y, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_unary_bwd(int kind, const float* dy, const float* x, long long n, float* dx, int accumulate, void* st) {
+  OPCHECK(dy && x && dx && n > 0 && (kind == 0 || kind == 1), "dhw_op_unary_bwd");
+  THIP(launch_unary_bwd(kind, dy, x, n, dx, accumulate, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_add(const float* a, const float* b, long long n, float* out, int accumulate, void* st) {
+  OPCHECK(a && out && n > 0, "dhw_op_add");
+  THIP(launch_add2(a, b, n, out, accumulate, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_add_rows(const float* x, const float* table, int B, int L, int C, float* out, void* st) {
+  OPCHECK(x && table && out && B > 0 && L > 0 && C > 0, "dhw_op_add_rows");
+  THIP(launch_add_rows(x, table, (long)B * L * C, (long)L * C, out, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_film(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, float* y, void* st) {
+  OPCHECK(x && gamma && beta && y && B > 0 && L > 0 && C > 0, "dhw_op_film");
+  THIP(launch_film_fwd(x, gamma, beta, pstride, B, L, C, y, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_film_bwd(const float* dy, const float* x, const float* gamma, long long pstride, int B, int L, int C, float* dx, int accumulate,
+                    float* dgamma, float* dbeta, void* st) {
+  OPCHECK(dy && x && gamma && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0, "dhw_op_film_bwd");
+  THIP(launch_film_bwd2(dy, x, gamma, pstride, B, L, C, dx, accumulate, dgamma, dbeta, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* st) {
+  OPCHECK(x && y && mean && rstd && rows > 0 && C > 0, "dhw_op_layernorm");
+  THIP(launch_ln_fwd(x, rows, C, y, mean, rstd, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_layernorm_bwd(const float* dy, const float* y, const float* rstd, long long rows, int C, float* dx, int accumulate, void* st) {
+  OPCHECK(dy && y && rstd && dx && rows > 0 && C > 0, "dhw_op_layernorm_bwd");
+  THIP(launch_ln_bwd(dy, y, rstd, rows, C, dx, accumulate, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_softmax(const float* s, long long rows, int cols, long long rows_per_sample, const float* mask, float scale, float* p, void* st) {
+  OPCHECK(s && p && rows > 0 && cols > 0 && rows_per_sample > 0, "dhw_op_softmax");
+  THIP(launch_softmax_fwd(s, rows, cols, rows_per_sample, mask, scale, p, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_softmax_bwd(const float* dp, const float* p, long long rows, int cols, float scale, float* ds, void* st) {
+  OPCHECK(dp && p && ds && rows > 0 && cols > 0, "dhw_op_softmax_bwd");
+  THIP(launch_softmax_bwd(dp, p, rows, cols, scale, ds, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_resample(int mode, const float* x, long long rows_out, int C, float* y, int accumulate, void* st) {
+  OPCHECK(x && y && rows_out > 0 && C > 0 && mode >= 0 && mode <= 3, "dhw_op_resample");
+  THIP(launch_pool(mode, x, rows_out * C, C, y, accumulate, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_embedding(const int64_t* ids, const float* table, long long rows, int C, float* y, void* st) {
+  OPCHECK(ids && table && y && rows > 0 && C > 0, "dhw_op_embedding");
+  THIP(launch_embed(0, ids, table, rows * C, C, y, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_embedding_bwd(const int64_t* ids, const float* dy, long long rows, int C, float* dtable, void* st) {
+  OPCHECK(ids && dy && dtable && rows > 0 && C > 0, "dhw_op_embedding_bwd");
+  THIP(launch_embed(1, ids, dy, rows * C, C, dtable, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_mask_mul(const float* x, const float* mask, float scale, long long n, float* y, int accumulate, void* st) {
+  OPCHECK(x && mask && y && n > 0, "dhw_op_mask_mul");
+  THIP(launch_mask_mul(x, mask, scale, n, y, accumulate, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_colsum(const float* dy, long long rows, int C, float* db, void* st) {
+  OPCHECK(dy && db && rows > 0 && C > 0, "dhw_op_colsum");
+  THIP(launch_colsum(dy, rows, C, db, (hipStream_t)st));
+  return 0;
+}
+
 }  // extern "C"

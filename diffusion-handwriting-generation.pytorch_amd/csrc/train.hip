@@ -260,3 +260,275 @@ hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const 
   hipLaunchKernelGGL(film_linear_bwd_kernel, dim3(nb(std::max((long)cols * 32, (long)B * 32))), dim3(256), 0, st, dfilm, sigma, wcat, B, cols, dw, db, dsigma);
   return hipGetLastError();
 }
+
+// =====================================================================================================================
+// Generic fp32 building blocks of the training step (dhw_train.h "dhw_op_*"): everything the denoiser's forward and
+// backward need beyond the fused inference kernels, each a plain device-pointer operation so the host side
+// (train_model.py) can chain them the way autograd chains the reference's modules.  Correctness first: the GEMM reads its
+// operands straight from global memory with caller-given strides (one description covers Linear / Conv1d forward,
+// data gradient, weight gradient and the per-head attention products), on the exact-f32 MFMA.
+namespace {
+
+// C[z][m][n] (+)= alpha * sum_k A(z, m, k) * B(z, k, n) (+ bias[n]);  z = zo * nzi + zi (two batch levels, e.g. sample x head)
+//   A(z,m,k) = A[zo*sazo + zi*sazi + (m + a_shift)*sam + k*sak], zero unless (m mod lr) + a_shift in [0, lr)   (lr = 0: no shift)
+//   B(z,k,n) = B[zo*sbzo + zi*sbzi + (k + b_shift)*sbk + n*sbn], zero unless (k mod lr) + b_shift in [0, lr)
+// One wave = one 16 x 16 tile of C; the K loop steps 32 (8 x v_mfma_f32_16x16x4_f32).
+__global__ __launch_bounds__(256) void sgemm_kernel(const OpGemm g) {
+  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  const int tiles_n = (g.N + 15) / 16, tiles_m = (g.M + 15) / 16;
+  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= (long)tiles_m * tiles_n) return;
+  const int m0 = (int)(tile / tiles_n) * 16, n0 = (int)(tile % tiles_n) * 16;
+  const int z = blockIdx.y, zo = z / g.nzi, zi = z % g.nzi;
+  const float* A = g.A + zo * g.sazo + zi * g.sazi;
+  const float* B = g.B + zo * g.sbzo + zi * g.sbzi;
+  float* C = g.C + zo * g.sczo + zi * g.sczi;
+  const int m = m0 + i, n = n0 + i;
+  bool a_ok = m < g.M;
+  long a_row = m;
+  if (g.lr > 0 && g.a_shift != 0) {
+    const int l = m % g.lr + g.a_shift;
+    a_ok = a_ok && l >= 0 && l < g.lr;
+    a_row = m + g.a_shift;
+  }
+  const bool b_ok = n < g.N;
+  f32x4 acc = (f32x4){0, 0, 0, 0};
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    Frag<float> fa, fb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 8 * q + j;
+      float va = 0.f, vb = 0.f;
+      if (k < g.K) {
+        if (a_ok) va = A[a_row * g.sam + (long)k * g.sak];
+        if (b_ok) {
+          bool ok = true;
+          long kr = k;
+          if (g.lr > 0 && g.b_shift != 0) {
+            const int l = k % g.lr + g.b_shift;
+            ok = l >= 0 && l < g.lr;
+            kr = k + g.b_shift;
+          }
+          if (ok) vb = B[kr * g.sbk + (long)n * g.sbn];
+        }
+      }
+      if (j < 4) { fa.lo[j] = va; fb.lo[j] = vb; } else { fa.hi[j - 4] = va; fb.hi[j - 4] = vb; }
+    }
+    mma32(acc, fa, fb);
+  }
+  // acc[r] = C[m0 + 4q + r][n0 + i]
+  if (n0 + i < g.N) {
+    const float bias = g.bias ? g.bias[n0 + i] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mm = m0 + 4 * q + r;
+      if (mm < g.M) {
+        float* c = C + (long)mm * g.scm + (long)(n0 + i) * g.scn;
+        const float v = g.alpha * acc[r] + bias;
+        *c = g.accumulate ? *c + v : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unary_kernel(int kind, const float* x, long n, float* y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  y[i] = kind == 0 ? silu_f(v) : sigmoid_f(v);
+}
+// kind 0: dx (+)= dy * SiLU'(x);  kind 1: dx (+)= dy * y (1 - y) with y = sigmoid output passed as x
+__global__ __launch_bounds__(256) void unary_bwd_kernel(int kind, const float* dy, const float* x, long n, float* dx, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = kind == 0 ? dy[i] * dsilu_f(x[i]) : dy[i] * x[i] * (1.0f - x[i]);
+  dx[i] = accumulate ? dx[i] + v : v;
+}
+// out = a + b (b may be null: copy);  accumulate: out += a (+ b)
+__global__ __launch_bounds__(256) void add_kernel2(const float* a, const float* b, long n, float* out, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = a[i] + (b ? b[i] : 0.f);
+  out[i] = accumulate ? out[i] + v : v;
+}
+// out[b][l][c] = x[b][l][c] + table[l][c]   (positional encodings: a constant, no gradient)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* x, const float* table, long n, long per_sample, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] + table[i % per_sample];
+}
+// y = x * gamma[b] + beta[b] (per-sample [B][C] rows at given strides)
+__global__ __launch_bounds__(256) void film_fwd_kernel(const float* x, const float* gam, const float* bet, long pstride, int L, int C, long n, float* y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C), b = (int)(r / L);
+  y[i] = x[i] * gam[b * pstride + c] + bet[b * pstride + c];
+}
+// LayerNorm(eps 1e-6, no affine) over the C channels of each row; one wave per row; keeps mean / rstd for the backward
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, long rows, int C, float* y, float* mean_out, float* rstd_out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = rsqrtf(v / C + 1e-6f);
+  for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd;
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+// dx (+)= rstd * (dy - mean(dy) - y * mean(dy * y)),  y = the normalised output
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* y, const float* rstd, long rows, int C, float* dx, int accumulate) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* d = dy + row * C;
+  const float* yr = y + row * C;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) { s1 += d[c]; s2 += d[c] * yr[c]; }
+  for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  s1 /= C; s2 /= C;
+  const float r = rstd[row];
+  for (int c = lane; c < C; c += 64) {
+    const float v = r * (d[c] - s1 - yr[c] * s2);
+    dx[row * C + c] = accumulate ? dx[row * C + c] + v : v;
+  }
+}
+// P = softmax(S * scale + mask[b][key] * (-1e9)) over the `cols` keys of each row; rows are [B][H][Lq], mask [B][cols] or null
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + row * cols;
+  const float* mr = mask ? mask + (row / rows_per_sample) * cols : nullptr;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, sr[c] * scale + (mr ? mr[c] * -1e9f : 0.f));
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += expf(sr[c] * scale + (mr ? mr[c] * -1e9f : 0.f) - mx);
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+  for (int c = lane; c < cols; c += 64) p[row * cols + c] = expf(sr[c] * scale + (mr ? mr[c] * -1e9f : 0.f) - mx) / sum;
+}
+// dS = scale * P * (dP - sum_key(dP * P))
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* dp, const float* p, long rows, int cols, float scale, float* ds) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += dp[row * cols + c] * p[row * cols + c];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  for (int c = lane; c < cols; c += 64) ds[row * cols + c] = scale * p[row * cols + c] * (dp[row * cols + c] - s);
+}
+// AvgPool1d(2) over rows / its backward;  nearest x2 upsampling / its backward  (rows C-last, L even)
+__global__ __launch_bounds__(256) void pool_kernel(int mode, const float* x, long n_out, int C, float* y, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  float v;
+  if (mode == 0) v = 0.5f * (x[(2 * r) * C + c] + x[(2 * r + 1) * C + c]);      // pool fwd: out row r <- rows 2r, 2r+1
+  else if (mode == 1) v = 0.5f * x[(r / 2) * C + c];                              // pool bwd: dx row r <- 0.5 dy[r/2]
+  else if (mode == 2) v = x[(r / 2) * C + c];                                     // upsample fwd: out row r <- row r/2
+  else v = x[(2 * r) * C + c] + x[(2 * r + 1) * C + c];                           // upsample bwd: dx row r <- dy[2r] + dy[2r+1]
+  y[i] = accumulate ? y[i] + v : v;
+}
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, const float* table, long n, int C, float* y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = table[ids[i / C] * C + i % C];
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, const float* dy, long n, int C, float* dtable) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(dtable + ids[i / C] * C + i % C, dy[i]);
+}
+// y = x * mask * scale (dropout with a supplied keep-mask; also its own backward)
+__global__ __launch_bounds__(256) void mask_mul_kernel(const float* x, const float* mask, float scale, long n, float* y, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i] * mask[i] * scale;
+  y[i] = accumulate ? y[i] + v : v;
+}
+// FiLM backward without activation for per-sample [B][C] parameter rows: du (+)= d * gamma, dgamma[b][c] += sum_l d u, dbeta += sum_l d
+__global__ __launch_bounds__(64) void film_bwd2_kernel(const float* d, const float* u, const float* gam, long pstride, int L, int C, float* du, int accumulate,
+                                                        float* dgam, float* dbet) {
+  const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  const float ga = gam[b * pstride + c];
+  float sg = 0.f, sb = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const long e = ((long)b * L + l) * C + c;
+    const float dd = d[e];
+    sg += dd * u[e];
+    sb += dd;
+    du[e] = accumulate ? du[e] + dd * ga : dd * ga;
+  }
+  dgam[b * pstride + c] += sg;
+  dbet[b * pstride + c] += sb;
+}
+
+}  // namespace
+
+hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
+  if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1) return hipErrorInvalidValue;
+  const long tiles = (long)((g.M + 15) / 16) * ((g.N + 15) / 16);
+  hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)((tiles + 3) / 4), g.nzo * g.nzi), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(unary_kernel, dim3(nb(n)), dim3(256), 0, st, kind, x, n, y);
+  return hipGetLastError();
+}
+hipError_t launch_unary_bwd(int kind, const float* dy, const float* x, long n, float* dx, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(unary_bwd_kernel, dim3(nb(n)), dim3(256), 0, st, kind, dy, x, n, dx, accumulate);
+  return hipGetLastError();
+}
+hipError_t launch_add2(const float* a, const float* b, long n, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(add_kernel2, dim3(nb(n)), dim3(256), 0, st, a, b, n, out, accumulate);
+  return hipGetLastError();
+}
+hipError_t launch_add_rows(const float* x, const float* table, long n, long per_sample, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3(nb(n)), dim3(256), 0, st, x, table, n, per_sample, out);
+  return hipGetLastError();
+}
+hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, float* y, hipStream_t st) {
+  const long n = (long)B * L * C;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(nb(n)), dim3(256), 0, st, x, gam, bet, pstride, L, C, n, y);
+  return hipGetLastError();
+}
+hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, long pstride, int B, int L, int C, float* du, int accumulate, float* dgam,
+                            float* dbet, hipStream_t st) {
+  hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B), dim3(64), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
+  return hipGetLastError();
+}
+hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, y, mean, rstd);
+  return hipGetLastError();
+}
+hipError_t launch_ln_bwd(const float* dy, const float* y, const float* rstd, long rows, int C, float* dx, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, dy, y, rstd, rows, C, dx, accumulate);
+  return hipGetLastError();
+}
+hipError_t launch_softmax_fwd(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, s, rows, cols, rows_per_sample, mask, scale, p);
+  return hipGetLastError();
+}
+hipError_t launch_softmax_bwd(const float* dp, const float* p, long rows, int cols, float scale, float* ds, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, dp, p, rows, cols, scale, ds);
+  return hipGetLastError();
+}
+hipError_t launch_pool(int mode, const float* x, long n_out, int C, float* y, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(pool_kernel, dim3(nb(n_out)), dim3(256), 0, st, mode, x, n_out, C, y, accumulate);
+  return hipGetLastError();
+}
+hipError_t launch_embed(int bwd, const int64_t* ids, const float* src, long n, int C, float* dst, hipStream_t st) {
+  if (bwd) hipLaunchKernelGGL(embed_bwd_kernel, dim3(nb(n)), dim3(256), 0, st, ids, src, n, C, dst);
+  else hipLaunchKernelGGL(embed_fwd_kernel, dim3(nb(n)), dim3(256), 0, st, ids, src, n, C, dst);
+  return hipGetLastError();
+}
+hipError_t launch_mask_mul(const float* x, const float* mask, float scale, long n, float* y, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(nb(n)), dim3(256), 0, st, x, mask, scale, n, y, accumulate);
+  return hipGetLastError();
+}

@@ -1,0 +1,412 @@
+"""The whole training step of ``DiffusionModel`` on the MI355X (BASELINE configs[4]).
+
+``TrainModel`` runs the reference's ``DiffusionModel.forward`` in train mode (model.py:133-199) and the backward pass its
+``loss.backward()`` would run (train.py:55-60), as a chain of hand-written fp32 HIP operations (include/dhw_train.h
+``dhw_op_*``: one strided exact-f32 MFMA GEMM for every Linear / Conv1d / attention product in all three directions, plus
+FiLM, LayerNorm, softmax, resampling, embedding and activation kernels).  torch supplies device memory and streams only:
+no torch operator touches an activation or a gradient.  The op order mirrors the reference module by module so that the
+recorded tape, replayed in reverse, accumulates exactly autograd's gradients; ``tests/test_gpu_train.py`` pins every one
+of the 323 parameter gradients against a fixture the imported reference generated (oracle/make_golden_r2.py).
+
+Parameters keep the reference's ``state_dict`` names and torch layouts, so a reference checkpoint loads unchanged and a
+trained one can be handed straight to ``dhg_amd.DiffusionModel`` for sampling.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .train import Adam, _stream, _tcheck, allreduce_grads, get_alphas, loss_fn, noam_lr, perturb
+
+_F = 4  # bytes per element
+
+
+class Var:
+    """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient."""
+    __slots__ = ("d", "g")
+
+    def __init__(self, d: torch.Tensor):
+        self.d = d
+        self.g = None
+
+    def grad(self) -> torch.Tensor:
+        if self.g is None:
+            self.g = torch.zeros_like(self.d)
+        return self.g
+
+
+def positional_encoding(length: int, dim: int, pos_factor: float) -> torch.Tensor:
+    """PosEmbeddings.forward(arange(length)) (attention.py:14-23) -> [length, dim] on the host (a constant table)."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = torch.arange(length)[:, None] * freq[None, :] * pos_factor
+    return torch.cat((e.sin(), e.cos()), dim=-1).float()
+
+
+class Tape:
+    """Forward ops append their backward closure; ``backward()`` replays them in reverse.  Every backward kernel ADDS into
+    the input's gradient buffer (zero-initialised on first touch), which is how autograd's fan-in sums arise."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.lib = _lib.lib()
+        self.st = _stream(device)
+        self.steps = []
+        self.launches = 0
+
+    # ---- raw kernel wrappers ---------------------------------------------------------------------------------------
+    def new(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
+             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0):
+        """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
+        def extent(off, s0, n0, s1, n1, z):
+            return off + (n0 - 1) * s0 + (n1 - 1) * s1 + (nzo - 1) * z[0] + (nzi - 1) * z[1]
+        if extent(a_off, sam, M, sak, K, za) >= A.numel() or extent(b_off, sbk, K, sbn, N, zb) >= Bm.numel() \
+                or extent(c_off, scm, M, scn, N, zc) >= Cm.numel() or min(a_off, b_off, c_off) < 0:
+            raise ValueError("gemm operand extents exceed their buffers")
+        if (a_shift or b_shift) and (lr < 1 or (M if a_shift else K) % lr):
+            raise ValueError("shifted gemm needs whole samples of lr rows")
+        d = _lib.GemmDesc(A.data_ptr() + a_off * _F, sam, sak, za[0], za[1], a_shift,
+                          Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], b_shift,
+                          Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
+                          M, N, K, nzo, nzi, lr, bias.data_ptr() if bias is not None else None, alpha, int(acc))
+        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
+        self.launches += 1
+
+    def call(self, fn, *args):
+        _tcheck(getattr(self.lib, fn)(*args, self.st))
+        self.launches += 1
+
+    # ---- differentiable ops ------------------------------------------------------------------------------------------
+    def linear(self, x: Var, W: Var, b: Var | None) -> Var:
+        """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]."""
+        R, K = x.d.shape
+        N = W.d.shape[0]
+        y = Var(self.new(R, N))
+        self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None)
+
+        def bwd():
+            dy = y.g
+            self.gemm(dy, 0, N, 1, W.d, 0, K, 1, x.grad(), 0, K, 1, R, K, N, acc=True)          # dx += dy W
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R, acc=True)          # dW += dy^T x
+            if b is not None:
+                self.call("dhw_op_colsum", dy.data_ptr(), R, N, b.grad().data_ptr())
+        self.record(y, bwd)
+        return y
+
+    def conv3(self, x: Var, W: Var, b: Var, L: int) -> Var:
+        """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout]."""
+        R, Cin = x.d.shape
+        Cout = W.d.shape[0]
+        y = Var(self.new(R, Cout))
+        for t in range(3):
+            self.gemm(x.d, 0, Cin, 1, W.d, t, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
+                      a_shift=t - 1, lr=L)
+
+        def bwd():
+            dy, dx, dW = y.g, x.grad(), W.grad()
+            for t in range(3):
+                # dx[r] += dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
+                self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=True, a_shift=1 - t, lr=L)
+                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L)
+            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, b.grad().data_ptr())
+        self.record(y, bwd)
+        return y
+
+    def unary(self, kind: int, x: Var) -> Var:
+        y = Var(torch.empty_like(x.d))
+        n = x.d.numel()
+        self.call("dhw_op_unary", kind, x.d.data_ptr(), n, y.d.data_ptr())
+        saved = x.d if kind == 0 else y.d
+        self.record(y, lambda: self.call("dhw_op_unary_bwd", kind, y.g.data_ptr(), saved.data_ptr(), n, x.grad().data_ptr(), 1))
+        return y
+
+    def silu(self, x):
+        return self.unary(0, x)
+
+    def sigmoid(self, x):
+        return self.unary(1, x)
+
+    def add(self, a: Var, b: Var) -> Var:
+        y = Var(torch.empty_like(a.d))
+        n = a.d.numel()
+        self.call("dhw_op_add", a.d.data_ptr(), b.d.data_ptr(), n, y.d.data_ptr(), 0)
+
+        def bwd():
+            self.call("dhw_op_add", y.g.data_ptr(), None, n, a.grad().data_ptr(), 1)
+            self.call("dhw_op_add", y.g.data_ptr(), None, n, b.grad().data_ptr(), 1)
+        self.record(y, bwd)
+        return y
+
+    def add_rows(self, x: Var, table: torch.Tensor, B: int) -> Var:
+        R, Cc = x.d.shape
+        y = Var(torch.empty_like(x.d))
+        self.call("dhw_op_add_rows", x.d.data_ptr(), table.data_ptr(), B, R // B, Cc, y.d.data_ptr())
+        self.record(y, lambda: self.call("dhw_op_add", y.g.data_ptr(), None, x.d.numel(), x.grad().data_ptr(), 1))
+        return y
+
+    def film(self, x: Var, gamma: Var, beta: Var, B: int) -> Var:
+        """x * gamma[b] + beta[b] (conditioning.py:23-26); gamma, beta [B, C]."""
+        R, Cc = x.d.shape
+        L = R // B
+        y = Var(torch.empty_like(x.d))
+        self.call("dhw_op_film", x.d.data_ptr(), gamma.d.data_ptr(), beta.d.data_ptr(), Cc, B, L, Cc, y.d.data_ptr())
+        self.record(y, lambda: self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), gamma.d.data_ptr(), Cc, B, L, Cc,
+                                            x.grad().data_ptr(), 1, gamma.grad().data_ptr(), beta.grad().data_ptr()))
+        return y
+
+    def layernorm(self, x: Var) -> Var:
+        R, Cc = x.d.shape
+        y = Var(torch.empty_like(x.d))
+        mean, rstd = self.new(R), self.new(R)
+        self.call("dhw_op_layernorm", x.d.data_ptr(), R, Cc, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+        self.record(y, lambda: self.call("dhw_op_layernorm_bwd", y.g.data_ptr(), y.d.data_ptr(), rstd.data_ptr(), R, Cc,
+                                            x.grad().data_ptr(), 1))
+        return y
+
+    def resample(self, mode: int, x: Var) -> Var:
+        """mode 0: AvgPool1d(2); mode 2: Upsample(x2, nearest) — over the row axis of C-last rows (L even)."""
+        R, Cc = x.d.shape
+        Ro = R // 2 if mode == 0 else R * 2
+        y = Var(self.new(Ro, Cc))
+        self.call("dhw_op_resample", mode, x.d.data_ptr(), Ro, Cc, y.d.data_ptr(), 0)
+        self.record(y, lambda: self.call("dhw_op_resample", mode + 1, y.g.data_ptr(), R, Cc, x.grad().data_ptr(), 1))
+        return y
+
+    def embedding(self, ids: torch.Tensor, table: Var) -> Var:
+        R = ids.numel()
+        Cc = table.d.shape[1]
+        y = Var(self.new(R, Cc))
+        self.call("dhw_op_embedding", ids.data_ptr(), table.d.data_ptr(), R, Cc, y.d.data_ptr())
+        self.record(y, lambda: self.call("dhw_op_embedding_bwd", ids.data_ptr(), y.g.data_ptr(), R, Cc, table.grad().data_ptr()))
+        return y
+
+    def attention(self, q: Var, k: Var, v: Var, B: int, H: int, mask: torch.Tensor | None) -> Var:
+        """scaled_dp_attn over heads (attention.py:26-45, 77-87): q [B*Lq, H*D], k / v [B*Lk, H*D] -> [B*Lq, H*D].
+        Heads are addressed by strides (no split / merge copies)."""
+        HD = q.d.shape[1]
+        D = HD // H
+        Lq, Lk = q.d.shape[0] // B, k.d.shape[0] // B
+        scale = 1.0 / math.sqrt(D)
+        S = self.new(B, H, Lq, Lk)
+        P = self.new(B, H, Lq, Lk)
+        o = Var(self.new(B * Lq, HD))
+        zq, zk, zs = (Lq * HD, D), (Lk * HD, D), (H * Lq * Lk, Lq * Lk)
+        self.gemm(q.d, 0, HD, 1, k.d, 0, 1, HD, S, 0, Lk, 1, Lq, Lk, D, nzo=B, nzi=H, za=zq, zb=zk, zc=zs)             # S = Q K^T
+        self.call("dhw_op_softmax", S.data_ptr(), B * H * Lq, Lk, H * Lq, mask.data_ptr() if mask is not None else None, scale, P.data_ptr())
+        self.gemm(P, 0, Lk, 1, v.d, 0, HD, 1, o.d, 0, HD, 1, Lq, D, Lk, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)             # O = P V
+
+        def bwd():
+            do = o.g
+            dP = S   # the scores are dead after the softmax: reuse their buffer
+            self.gemm(P, 0, 1, Lk, do, 0, HD, 1, v.grad(), 0, HD, 1, Lk, D, Lq, acc=True, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)   # dV += P^T dO
+            self.gemm(do, 0, HD, 1, v.d, 0, 1, HD, dP, 0, Lk, 1, Lq, Lk, D, nzo=B, nzi=H, za=zq, zb=zk, zc=zs)               # dP = dO V^T
+            self.call("dhw_op_softmax_bwd", dP.data_ptr(), P.data_ptr(), B * H * Lq, Lk, scale, dP.data_ptr())                # dS (in place)
+            self.gemm(dP, 0, Lk, 1, k.d, 0, HD, 1, q.grad(), 0, HD, 1, Lq, D, Lk, acc=True, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)  # dQ += dS K
+            self.gemm(dP, 0, 1, Lk, q.d, 0, HD, 1, k.grad(), 0, HD, 1, Lk, D, Lq, acc=True, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)  # dK += dS^T Q
+        self.record(o, bwd)
+        return o
+
+    def dropout(self, x: Var, keep: torch.Tensor, p: float) -> Var:
+        """nn.Dropout(p) with the keep-mask supplied (1 = kept)."""
+        y = Var(torch.empty_like(x.d))
+        n = x.d.numel()
+        scale = 1.0 / (1.0 - p)
+        self.call("dhw_op_mask_mul", x.d.data_ptr(), keep.data_ptr(), scale, n, y.d.data_ptr(), 0)
+        self.record(y, lambda: self.call("dhw_op_mask_mul", y.g.data_ptr(), keep.data_ptr(), scale, n, x.grad().data_ptr(), 1))
+        return y
+
+    def backward(self):
+        for step in reversed(self.steps):
+            step()
+        self.steps = []
+
+    def record(self, out: Var, fn):
+        """fn runs in the backward sweep iff a gradient reached ``out``."""
+        self.steps.append(lambda: fn() if out.g is not None else None)
+
+
+class TrainModel:
+    """``DiffusionModel`` (model.py:61-199) for training: parameters as fp32 device tensors under the reference's names."""
+
+    STYLE_DROP = 0.3   # text_style.py:88
+
+    def __init__(self, state_dict: dict, num_layers: int = 2, device=None, drop_rate: float = 0.0):
+        if drop_rate != 0.0:
+            # configs/best.yml trains with dropout 0.0; only the TextStyleEncoder's fixed Dropout(0.3) is active
+            raise NotImplementedError("EncoderLayer dropout > 0 is not built; the reference's training config uses 0.0")
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrainModel needs the MI355X: the training step has no CPU path")
+        self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.num_layers = num_layers
+        self.names = list(state_dict.keys())
+        self.p = {k: Var(torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(self.dev, torch.float32).contiguous())
+                  for k, v in state_dict.items()}
+        self.c1 = self.p["input_dense.weight"].d.shape[0]
+        self._pe = {}
+        self.tape = None
+
+    # ---- parameters ------------------------------------------------------------------------------------------------------
+    def parameters(self):
+        return [self.p[k].d for k in self.names]
+
+    def grads(self):
+        return [self.p[k].grad() for k in self.names]
+
+    def zero_grad(self):
+        for v in self.p.values():
+            if v.g is not None:
+                v.g.zero_()   # hipMemset
+
+    def state_dict(self):
+        return {k: self.p[k].d for k in self.names}
+
+    def pe(self, L, dim, factor):
+        key = (L, dim, factor)
+        if key not in self._pe:
+            self._pe[key] = positional_encoding(L, dim, factor).to(self.dev)
+        return self._pe[key]
+
+    # ---- modules ---------------------------------------------------------------------------------------------------------
+    def _lin(self, t, x, name):
+        return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
+
+    def _ffn(self, t, x, name):
+        """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear."""
+        return self._lin(t, t.silu(self._lin(t, t.silu(x), name + ".1")), name + ".3")
+
+    def _affine(self, t, x, sigma, name, B):
+        return t.film(x, self._lin(t, sigma, name + ".gamma_emb"), self._lin(t, sigma, name + ".beta_emb"), B)
+
+    def _mha(self, t, q, k, v, name, B, H, mask=None):
+        o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
+        return self._lin(t, o, name + ".dense")
+
+    def _convblock(self, t, x, sigma, name, B, L):
+        """cnn.py:64-87."""
+        conv = lambda v, n: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L)   # noqa: E731
+        skip = conv(x, "conv_skip")
+        h = self._affine(t, conv(t.silu(x), "conv1"), sigma, name + ".affine1", B)
+        h = self._affine(t, conv(t.silu(h), "conv2"), sigma, name + ".affine2", B)
+        h = self._affine(t, self._lin(t, t.silu(h), name + ".fc"), sigma, name + ".affine3", B)
+        return t.add(h, skip)
+
+    def _encoder(self, t, x, text, sigma, mask, name, B, H, pos_factor):
+        """EncoderLayer.forward (model.py:36-58) with drop_rate 0."""
+        d = x.d.shape[1]
+        Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
+        tx = self._affine(t, t.layernorm(self._lin(t, t.silu(text), name + ".text_dense")), sigma, name + ".affine0", B)
+        text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
+        x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
+        x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
+        x2 = t.add(self._affine(t, t.layernorm(x2), sigma, name + ".affine1", B), x)
+        x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)
+        x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
+        x3 = self._affine(t, t.layernorm(t.add(x2, x3)), sigma, name + ".affine2", B)
+        x4 = t.add(self._ffn(t, x3, name + ".ffn"), x3)
+        return self._affine(t, t.layernorm(x4), sigma, name + ".affine3", B)
+
+    def _text_style(self, t, ids, style, sigma, keep, B):
+        """TextStyleEncoder.forward (text_style.py:96-110)."""
+        n = "text_style_model"
+        S = style.d.shape[1]
+        st = t.dropout(style, keep, self.STYLE_DROP)                          # [B, S, 1280]
+        up = _ViewVar(st, (B * S * 5, st.d.shape[2] // 5))                      # reshape_up(., 5): a pure view of the same rows
+        stf = self._ffn(t, up, n + ".style_ffn")
+        stf = self._affine(t, t.layernorm(stf), sigma, n + ".affine1", B)
+        tx = t.embedding(ids, self.p[n + ".emb.weight"])
+        tx = self._affine(t, t.layernorm(tx), sigma, n + ".affine2", B)
+        m = self._mha(t, tx, stf, stf, n + ".mha", B, 8)
+        tx = self._affine(t, t.layernorm(t.add(tx, m)), sigma, n + ".affine3", B)
+        return self._affine(t, t.layernorm(self._ffn(t, tx, n + ".text_ffn")), sigma, n + ".affine4", B)
+
+    # ---- forward / backward ----------------------------------------------------------------------------------------------
+    def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style: torch.Tensor, style_keep: torch.Tensor | None = None):
+        """strokes [B, L, 2], text int64 [B, Lt], sigma [B, 1] (= sqrt(abar), train.py:49), style [B, S, 1280];
+        ``style_keep``: the Dropout(0.3) keep-mask [B, S, 1280] (drawn here when omitted).  -> (score [B, L, 2], pen [B, L])."""
+        dev = self.dev
+        B, L, _ = strokes.shape
+        if L % 8:
+            raise ValueError("the stroke length must be a multiple of 8 (three AvgPool1d(2) stages)")
+        t = self.tape = Tape(dev)
+        f = lambda a: a.to(dev, torch.float32).contiguous()   # noqa: E731
+        ids = text.to(dev, torch.int64).contiguous()
+        if int(text.min()) < 0 or int(text.max()) >= self.p["text_style_model.emb.weight"].d.shape[0]:
+            raise ValueError("token id out of the embedding's range")
+        mask = (text == 0).to(torch.float32).to(dev).contiguous()          # create_padding_mask (utils/nn.py:189), host side
+        if style_keep is None:
+            style_keep = (torch.rand(style.shape) >= self.STYLE_DROP).float()
+        keep = f(style_keep)
+        x_in, sig_in, sty = Var(f(strokes).view(B * L, 2)), Var(f(sigma).view(B, 1)), Var(f(style))
+
+        sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
+        txt = self._text_style(t, ids, sty, sigma_v, keep, B)                          # [B*Lt, 2 c2]
+        x = self._lin(t, x_in, "input_dense")
+        h1 = self._convblock(t, x, sigma_v, "enc1", B, L)
+        h2 = self._convblock(t, t.resample(0, h1), sigma_v, "enc2", B, L // 2)
+        h2 = self._encoder(t, h2, txt, sigma_v, mask, "enc3", B, 3, 4)
+        h3 = self._convblock(t, t.resample(0, h2), sigma_v, "enc4", B, L // 4)
+        h3 = self._encoder(t, h3, txt, sigma_v, mask, "enc5", B, 4, 2)
+        x = self._lin(t, t.resample(0, h3), "att_dense")
+        for i in range(self.num_layers):
+            x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1)
+        skip = lambda v, n, Lr: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr)   # noqa: E731
+        x = self._convblock(t, t.add(t.resample(2, x), skip(h3, "skip_conv3", L // 4)), sigma_v, "dec3", B, L // 4)
+        x = self._convblock(t, t.add(t.resample(2, x), skip(h2, "skip_conv2", L // 2)), sigma_v, "dec2", B, L // 2)
+        x = self._convblock(t, t.add(t.resample(2, x), skip(h1, "skip_conv1", L)), sigma_v, "dec1", B, L)
+        self._score = self._lin(t, x, "output_dense")
+        self._pen = t.sigmoid(self._lin(t, x, "pen_lifts_dense.0"))
+        return self._score.d.view(B, L, 2), self._pen.d.view(B, L)
+
+    def backward(self, d_score: torch.Tensor, d_pen: torch.Tensor):
+        """Accumulate every parameter gradient for the upstream gradients of the two outputs."""
+        self._score.g = d_score.contiguous().view_as(self._score.d)
+        self._pen.g = d_pen.contiguous().view_as(self._pen.d)
+        self.tape.backward()
+        self.tape = None
+
+
+class _ViewVar(Var):
+    """A reshaped alias of another Var: shares the data AND the gradient storage (reshape_up is a pure view)."""
+    __slots__ = ("base", "shape")
+
+    def __init__(self, base: Var, shape):
+        self.base, self.shape = base, shape
+        self.d = base.d.view(*shape)
+        self.g = None
+
+    def grad(self):
+        if self.g is None:
+            self.g = self.base.grad().view(*self.shape)
+        return self.g
+
+
+def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch.Tensor, step: int, *, eps: torch.Tensor | None = None,
+               alphas: torch.Tensor | None = None, style_keep: torch.Tensor | None = None, d_model: int = 256,
+               warmup: int = 10000, lr_mul: float = 1.0):
+    """One update, in the reference's order (train.py:26-67): abar draw, eps draw, perturbation, forward, loss, backward,
+    (data-parallel gradient mean when torch.distributed is initialised), clip + Adam at the Noam rate of update number ``step`` >= 1.
+    batch: {"strokes" [B,L,3], "text" [B,Lt], "style" [B,S,1280]}.  Returns the device tensor (loss, score_loss, pen_loss)."""
+    strokes3 = batch["strokes"]
+    x, pen = strokes3[:, :, :2].float(), strokes3[:, :, 2].float()
+    B = x.shape[0]
+    if alphas is None:
+        alphas = get_alphas(B, alpha_set)                    # [B, 1], torch's CPU generator like the reference
+    if eps is None:
+        eps = torch.randn(x.shape)
+    x_pert = perturb(x, eps, alphas)
+    model.zero_grad()
+    score, pen_pred = model.forward(x_pert, batch["text"], torch.sqrt(alphas), batch["style"], style_keep)
+    out, d_score, d_pen = loss_fn(eps, score, pen, pen_pred, alphas)
+    model.backward(d_score, d_pen)
+    grads = model.grads()
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        allreduce_grads(grads)
+    model.last_grad_norm = float(optimizer.step(grads, noam_lr(step, d_model, warmup, lr_mul)))   # (one host sync per update)
+    return out

@@ -7,8 +7,10 @@
  *   dhw_train_loss       <- loss_fn (loss.py:5-37) and d loss / d(score_pred, pen_lifts_pred)     (loss.backward())
  *   dhw_train_adam       <- clip_grad_norm_(max_norm) (utils/clip_grad.py:42-43) + torch.optim.Adam (configs/best.yml:33-38)
  *   dhw_train_convblock  <- ConvBlock.forward + its autograd backward (cnn.py:64-87): the first block of the denoiser's
- *                           backward pass; the EncoderLayer / TextStyleEncoder backward kernels are not built yet, so a
- *                           whole train_step cannot run natively — see DESIGN.md.
+ *                           backward pass as ONE fused entry point (weights packed per call).
+ *   dhw_op_*             <- the generic fp32 operations from which dhg_amd/train_model.py assembles the WHOLE
+ *                           DiffusionModel forward (train mode) and backward — every parameter gradient of the
+ *                           reference's loss.backward() (train.py:55-60).
  *
  * fp32; activations are C-last [B*L, C] device buffers; weights of dhw_train_convblock are HOST pointers in torch layouts
  * (packed per call: this entry point is a gradient-parity vehicle, not yet a tuned trainer).
@@ -53,6 +55,53 @@ typedef struct {   /* DEVICE pointers, the same layouts */
 int dhw_train_convblock(int device, int B, int L, int cin, int cout, const float* x, const float* sigma, const float* dout,
                         const dhw_convblock_weights* w, float* out, float* dx, float* dsigma, const dhw_convblock_grads* g,
                         void* hip_stream);
+
+/* ---- generic fp32 operations of the training step (DiffusionModel.forward in train mode + its autograd backward) -------
+ * The host side (dhg_amd/train_model.py) chains these the way autograd chains the reference's modules; every pointer is a
+ * DEVICE pointer to f32 (ids: int64), activations are C-last rows [B*L, C], weights stay in torch layouts (no packing:
+ * the GEMM takes strides).  `accumulate` != 0 adds into the destination (gradient fan-in) instead of overwriting it. */
+
+typedef struct {
+  /* C[z][m][n] (+)= alpha * sum_k A(z,m,k) B(z,k,n) (+ bias[n]);  z = zo * nzi + zi  (two batch levels, e.g. sample x head)
+   *   A(z,m,k) = A[zo*sazo + zi*sazi + (m + a_shift)*sam + k*sak], taken as 0 unless (m mod lr) + a_shift is in [0, lr)
+   *   B(z,k,n) = B[zo*sbzo + zi*sbzi + (k + b_shift)*sbk + n*sbn], taken as 0 unless (k mod lr) + b_shift is in [0, lr)
+   * lr = rows per sample for the Conv1d taps ('same' zero padding inside each sample; 0 = no shifting).  One description
+   * covers nn.Linear / Conv1d forward, data gradient and weight gradient and the per-head attention products. */
+  const float* A; long long sam, sak, sazo, sazi; int a_shift;
+  const float* B; long long sbk, sbn, sbzo, sbzi; int b_shift;
+  float* C; long long scm, scn, sczo, sczi;
+  int M, N, K, nzo, nzi, lr;
+  const float* bias; float alpha; int accumulate;
+} dhw_gemm_desc;
+
+int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
+/* kind 0: SiLU, 1: sigmoid.  Backward: kind 0 takes the forward INPUT x, kind 1 the forward OUTPUT y. */
+int dhw_op_unary(int kind, const float* x, long long n, float* y, void* hip_stream);
+int dhw_op_unary_bwd(int kind, const float* dy, const float* x_or_y, long long n, float* dx, int accumulate, void* hip_stream);
+/* out (+)= a + b   (b may be NULL) */
+int dhw_op_add(const float* a, const float* b, long long n, float* out, int accumulate, void* hip_stream);
+/* out[b][l][c] = x[b][l][c] + table[l][c]: the constant positional encodings (model.py:48, text_style.py:56) */
+int dhw_op_add_rows(const float* x, const float* table, int B, int L, int C, float* out, void* hip_stream);
+/* AffineTransformLayer (conditioning.py:20-26) given its gamma / beta rows [B][C] (row stride pstride) */
+int dhw_op_film(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, float* y, void* hip_stream);
+int dhw_op_film_bwd(const float* dy, const float* x, const float* gamma, long long pstride, int B, int L, int C, float* dx, int accumulate,
+                    float* dgamma, float* dbeta /* += */, void* hip_stream);
+/* nn.LayerNorm(C, eps=1e-6, elementwise_affine=False) over each row; rstd [rows] is kept for the backward, which takes y */
+int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* hip_stream);
+int dhw_op_layernorm_bwd(const float* dy, const float* y, const float* rstd, long long rows, int C, float* dx, int accumulate, void* hip_stream);
+/* attention.py:16-22: P = softmax(S * scale + mask * -1e9) over `cols` keys; rows = B*H*Lq, mask [B][cols] or NULL */
+int dhw_op_softmax(const float* s, long long rows, int cols, long long rows_per_sample, const float* mask, float scale, float* p, void* hip_stream);
+int dhw_op_softmax_bwd(const float* dp, const float* p, long long rows, int cols, float scale, float* ds, void* hip_stream);
+/* mode 0: AvgPool1d(2) forward (rows_out = rows_in / 2), 1: its backward (rows_out = 2 rows_in), 2: nearest x2 Upsample
+ * forward (rows_out = 2 rows_in), 3: its backward (rows_out = rows_in / 2).  L is even, so sample boundaries are kept. */
+int dhw_op_resample(int mode, const float* x, long long rows_out, int C, float* y, int accumulate, void* hip_stream);
+/* nn.Embedding forward (rows ids -> [rows, C]) and backward (dtable += scatter of dy) */
+int dhw_op_embedding(const int64_t* ids, const float* table, long long rows, int C, float* y, void* hip_stream);
+int dhw_op_embedding_bwd(const int64_t* ids, const float* dy, long long rows, int C, float* dtable, void* hip_stream);
+/* y (+)= x * mask * scale: nn.Dropout with a supplied keep-mask (scale = 1 / (1 - p)), and its backward */
+int dhw_op_mask_mul(const float* x, const float* mask, float scale, long long n, float* y, int accumulate, void* hip_stream);
+/* db[c] += sum over rows of dy[r][c]  (bias gradients) */
+int dhw_op_colsum(const float* dy, long long rows, int C, float* db, void* hip_stream);
 
 const char* dhw_train_last_error(void);
 

@@ -1,0 +1,196 @@
+"""The whole training step in HIP (dhg_amd/train_model.py over include/dhw_train.h dhw_op_*): each generic operation against
+torch's CPU operator + autograd on the same seeded inputs, then DiffusionModel forward + loss.backward() against the fixture
+the imported reference generated (tests/golden/model_grad.npz, oracle/make_golden_r2.py model_grad_fixture): outputs, losses
+and ALL 323 parameter gradients (norm + projection on a fixed random direction each, a few small ones element-wise)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dhg_amd
+from dhg_amd import spec, train, train_model as tm
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def probe(index: int, n: int) -> np.ndarray:
+    """The fixed random direction oracle/make_golden_r2.py projected parameter gradient number ``index`` on."""
+    return np.random.Generator(np.random.PCG64([77, index])).standard_normal(n).astype(np.float32)
+
+
+def _var(t):
+    return tm.Var(t.detach().to(DEV, torch.float32).contiguous())
+
+
+def _close(a, b, tol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-6)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert float((a - b).abs().max()) <= tol * scale, (float((a - b).abs().max()), scale)
+
+
+def _run(build, inputs, dout_seed=9):
+    """build(tape, *Vars) -> Var;  the same function on torch tensors gives the reference via autograd."""
+    g = torch.Generator().manual_seed(dout_seed)
+    tape = tm.Tape(torch.device(DEV))
+    vs = [_var(t) for t in inputs]
+    y = build(tape, *vs)
+    dy = torch.randn(y.d.shape, generator=g)
+    y.g = dy.to(DEV)
+    tape.backward()
+    torch.cuda.synchronize()
+    return y, vs, dy
+
+
+def test_linear_and_conv3_in_all_three_directions():
+    g = torch.Generator().manual_seed(1)
+    B, L, Cin, Cout = 3, 20, 40, 72          # not multiples of 16 / 32: the GEMM's edge masking
+    x = torch.randn(B * L, Cin, generator=g, requires_grad=True)
+    W = torch.randn(Cout, Cin, 3, generator=g, requires_grad=True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    y, (vx, vW, vb), dy = _run(lambda t, x, W, b: t.conv3(x, W, b, L), (x, W, b))
+    ref = F.conv1d(x.view(B, L, Cin).transpose(1, 2), W, b, padding="same").transpose(1, 2).reshape(B * L, Cout)
+    ref.backward(dy)
+    _close(y.d, ref)
+    _close(vx.g, x.grad)
+    _close(vW.g, W.grad)
+    _close(vb.g, b.grad)
+
+    x = torch.randn(50, 2, generator=g, requires_grad=True)                    # K = 2: input_dense
+    W = torch.randn(130, 2, generator=g, requires_grad=True)
+    b = torch.randn(130, generator=g, requires_grad=True)
+    y, (vx, vW, vb), dy = _run(lambda t, x, W, b: t.linear(x, W, b), (x, W, b))
+    ref = F.linear(x, W, b)
+    ref.backward(dy)
+    for mine, r in ((y.d, ref), (vx.g, x.grad), (vW.g, W.grad), (vb.g, b.grad)):
+        _close(mine, r)
+
+
+def test_attention_with_padding_mask():
+    g = torch.Generator().manual_seed(2)
+    B, H, D, Lq, Lk = 2, 3, 64, 24, 10
+    q = torch.randn(B * Lq, H * D, generator=g, requires_grad=True)
+    k = torch.randn(B * Lk, H * D, generator=g, requires_grad=True)
+    v = torch.randn(B * Lk, H * D, generator=g, requires_grad=True)
+    mask = torch.zeros(B, Lk)
+    mask[0, 7:] = 1
+    mask[1, 9:] = 1
+    y, (vq, vk, vv), dy = _run(lambda t, q, k, v: t.attention(q, k, v, B, H, mask.to(DEV)), (q, k, v))
+    split = lambda a, Ln: a.view(B, Ln, H, D).transpose(1, 2)   # noqa: E731
+    ref = F.scaled_dot_product_attention(split(q, Lq), split(k, Lk), split(v, Lk), attn_mask=mask[:, None, None, :] * -1e9)
+    ref = ref.transpose(1, 2).reshape(B * Lq, H * D)
+    ref.backward(dy)
+    for mine, r in ((y.d, ref), (vq.g, q.grad), (vk.g, k.grad), (vv.g, v.grad)):
+        _close(mine, r)
+
+
+def test_elementwise_norm_and_resampling_ops():
+    g = torch.Generator().manual_seed(3)
+    B, L, Cc = 2, 12, 96
+    x = torch.randn(B * L, Cc, generator=g, requires_grad=True)
+    gam = torch.randn(B, Cc, generator=g, requires_grad=True)
+    bet = torch.randn(B, Cc, generator=g, requires_grad=True)
+    pe = tm.positional_encoding(L, Cc, 4.0)
+    keep = (torch.rand(B * L, Cc, generator=g) > 0.3).float()
+
+    def build(t, x, gam, bet):
+        h = t.film(t.layernorm(t.silu(x)), gam, bet, B)
+        h = t.add(t.add_rows(h, pe.to(DEV), B), x)                      # fan-in on x
+        h = t.dropout(h, keep.to(DEV), 0.3)
+        h = t.resample(2, t.resample(0, h))                             # pool then upsample
+        return t.sigmoid(h)
+
+    y, (vx, vg, vb), dy = _run(build, (x, gam, bet))
+    h = F.layer_norm(F.silu(x), (Cc,), eps=1e-6).view(B, L, Cc) * gam[:, None] + bet[:, None]
+    h = (h + pe[None]).reshape(B * L, Cc) + x
+    h = h * keep / 0.7
+    h = F.avg_pool1d(h.view(B, L, Cc).transpose(1, 2), 2)
+    h = F.interpolate(h, scale_factor=2, mode="nearest").transpose(1, 2).reshape(B * L, Cc)
+    ref = torch.sigmoid(h)
+    ref.backward(dy)
+    for mine, r in ((y.d, ref), (vx.g, x.grad), (vg.g, gam.grad), (vb.g, bet.grad)):
+        _close(mine, r)
+
+
+def test_embedding_gather_and_scatter():
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(73, 48, generator=g, requires_grad=True)
+    ids = torch.randint(0, 73, (2, 9), generator=g)
+    y, (vt,), dy = _run(lambda t, table: t.embedding(ids.to(DEV).view(-1), table), (table,))
+    ref = F.embedding(ids.view(-1), table)
+    ref.backward(dy)
+    _close(y.d, ref)
+    _close(vt.g, table.grad)
+
+
+def test_whole_model_gradients_match_the_reference_autograd(golden_dir):
+    f = np.load(os.path.join(golden_dir, "model_grad.npz"))
+    B, L, Lt, S = (int(f[k]) for k in ("B", "L", "Lt", "S"))
+    sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    names = [str(n) for n in f["names"]]
+    assert names == [n for n in sd if n in set(names)] and len(names) == 323
+    inp = spec.synthetic_inputs(B, L, Lt, S=S, seed=int(f["seed"]), pad=int(f["pad"]))
+    keep = torch.from_numpy(np.unpackbits(f["keep"])[:B * S * 1280].reshape(B, S, 1280).astype(np.float32))
+    eps, pen, alphas = (torch.from_numpy(f[k]) for k in ("eps", "pen", "alphas"))
+
+    model = tm.TrainModel({k: sd[k] for k in names}, num_layers=2, device=DEV)
+    x_pert = train.perturb(torch.from_numpy(inp["strokes"]), eps, alphas)
+    _close(x_pert, torch.from_numpy(f["x_pert"]), 1e-6)
+    score, pen_pred = model.forward(x_pert, torch.from_numpy(inp["text"]), torch.sqrt(alphas), torch.from_numpy(inp["style"]), keep)
+    _close(score, torch.from_numpy(f["score"]), 5e-5)
+    _close(pen_pred, torch.from_numpy(f["pen_pred"]), 5e-5)
+    out, d_score, d_pen = train.loss_fn(eps, score, pen, pen_pred, alphas)
+    assert np.allclose(out.cpu().numpy(), f["loss"], rtol=2e-5)
+    model.backward(d_score, d_pen)
+    torch.cuda.synchronize()
+
+    # every parameter gradient: norm and projection on the fixture's random direction, relative to the gradient's own norm
+    # (floored at 1e-4 of the largest: a few gradients — key biases under the softmax's shift invariance — are exactly 0)
+    norms, dots = f["norms"], f["dots"]
+    floor = 1e-4 * norms.max()
+    worst = (0.0, "")
+    for i, n in enumerate(names):
+        gr = model.p[n].g
+        assert gr is not None, f"no gradient reached {n}"
+        gr = gr.cpu().double().numpy().ravel()
+        scale = max(norms[i], floor)
+        e_norm = abs(np.linalg.norm(gr) - norms[i]) / scale
+        e_dot = abs(np.dot(gr, probe(i, gr.size).astype(np.float64)) - dots[i]) / scale
+        worst = max(worst, (max(e_norm, e_dot), n))
+        assert e_norm < 2e-3 and e_dot < 2e-3, (n, e_norm, e_dot, norms[i])
+    print("worst parameter-gradient error (relative to its norm):", worst)
+    for k in f.files:
+        if k.startswith("g_"):
+            _close(model.p[k[2:]].g, torch.from_numpy(f[k]), 1e-3)
+
+
+def test_train_steps_follow_the_reference_trajectory(golden_dir):
+    """tests/golden/train_traj.npz: four updates of the reference's train_step (train.py:26-67) with its optimizer stack
+    (Adam + InvSqrtScheduledOptim + clip_grad_norm_(100), configs/best.yml) on one fixed batch.  The native step — perturb,
+    forward, loss, backward, clip, Adam at the Noam rate — must reproduce each step's three losses, the unclipped gradient
+    norm, and every parameter's displacement after the last update."""
+    f = np.load(os.path.join(golden_dir, "train_traj.npz"))
+    B, L, Lt, S, steps = (int(f[k]) for k in ("B", "L", "Lt", "S", "steps"))
+    sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    model = tm.TrainModel(sd, num_layers=2, device=DEV)
+    opt = train.Adam(model.parameters())
+    inp = spec.synthetic_inputs(B, L, Lt, S=S, seed=int(f["seed"]), pad=int(f["pad"]))
+    strokes3 = torch.cat([torch.from_numpy(inp["strokes"]), torch.from_numpy(f["pen"])[..., None]], dim=-1)
+    batch = {"strokes": strokes3, "text": torch.from_numpy(inp["text"]), "style": torch.from_numpy(inp["style"])}
+    eps, alphas = torch.from_numpy(f["eps"]), torch.from_numpy(f["alphas"])
+    keeps = np.unpackbits(f["keep"])[:steps * B * S * 1280].reshape(steps, B, S, 1280).astype(np.float32)
+    losses = []
+    for step in range(1, steps + 1):
+        out = tm.train_step(model, opt, batch, None, step, eps=eps, alphas=alphas, style_keep=torch.from_numpy(keeps[step - 1]),
+                            warmup=int(f["warmup"]))
+        losses.append(out.cpu().numpy())
+        assert abs(model.last_grad_norm - f["grad_norms"][step - 1]) < 2e-3 * f["grad_norms"][step - 1], (step, model.last_grad_norm)
+    losses = np.array(losses)
+    print("losses:", losses[:, 0], "reference:", f["losses"][:, 0])
+    assert np.allclose(losses, f["losses"], rtol=2e-3), (losses, f["losses"])
+    delta = np.array([float((model.p[n].d.cpu() - torch.from_numpy(sd[n])).norm()) for n in model.names])
+    assert np.allclose(delta, f["delta"], rtol=2e-2, atol=1e-6), np.abs(delta / np.maximum(f["delta"], 1e-12) - 1).max()

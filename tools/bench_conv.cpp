@@ -13,7 +13,7 @@ static void* dev_rand(size_t bytes, bool f32 = false) {
   return p;
 }
 int main(int argc, char** argv) {
-  const int B = 64, reps = argc > 1 ? atoi(argv[1]) : 30;
+  const int B = getenv("BENCH_B") ? atoi(getenv("BENCH_B")) : 64, reps = argc > 1 ? atoi(argv[1]) : 30;
   CK(convblock_init());
   struct Cfg { const char* n; int L, cin, cout, up; };   // up: channels of the skip activation (fused Upsample + skip_conv input) or 0
   const Cfg cfgs[] = {{"enc1", 488, 128, 128, 0}, {"enc2", 244, 128, 192, 0}, {"enc4", 122, 192, 256, 0}, {"dec3", 122, 384, 256, 0}, {"dec2", 244, 256, 192, 0}, {"dec1", 488, 192, 128, 0},
