@@ -4,6 +4,8 @@
 // the weight-gradient contraction over stroke rows on the exact-f32 MFMA, bias gradients, the FiLM Linear backward.
 // fp32 throughout (the gradients are checked against the reference's autograd at fp32 tolerances); the data-gradient
 // convolutions run on the generic GEMM kernel with transposed / tap-flipped packed weights (dhw_train_api.cpp).
+#include <cstdlib>
+
 #include "dhw_common.h"
 #include "dhw_kernels.h"
 
@@ -132,14 +134,17 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
   if (i < n) out[i] = a[i] + b[i];
 }
 
-// db[c] = sum over all rows of dy[r][c]: block = 64 channels x a chunk of rows, one atomic per (block, channel)
-__global__ __launch_bounds__(64) void colsum_kernel(const float* dy, long rows, int C, int rows_per_block, float* db) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
+// db[c] += sum over all rows of dy[r][c]: block = 64 channels x 4 row groups over a chunk of rows, one atomic per (block, channel)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* dy, long rows, int C, int rows_per_block, float* db) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += dy[r * C + c];
-  atomicAdd(db + c, s);
+  if (c < C)
+    for (long r = r0 + rg; r < r1; r += 4) s += dy[r * C + c];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) atomicAdd(db + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // Weight gradient of Conv1d(k = taps, 'same' zero padding inside each sample) / Linear (taps = 1), torch layout:
@@ -247,8 +252,8 @@ hipError_t launch_add(const float* a, const float* b, long n, float* out, hipStr
   return hipGetLastError();
 }
 hipError_t launch_colsum(const float* dy, long rows, int C, float* db, hipStream_t st) {   // db zeroed by the caller
-  const int rpb = 512;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb(C, 64), nb(rows, rpb)), dim3(64), 0, st, dy, rows, C, rpb, db);
+  const int rpb = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb(C, 64), nb(rows, rpb)), dim3(256), 0, st, dy, rows, C, rpb, db);
   return hipGetLastError();
 }
 hipError_t launch_wgrad(const float* dy, const float* x, int B, int L, int Cout, int Cin, int taps, float* dw, hipStream_t st) {   // dw zeroed by the caller
@@ -328,6 +333,117 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const OpGemm g) {
         *c = g.accumulate ? *c + v : v;
       }
     }
+  }
+}
+
+// The same contract, LDS-tiled: one workgroup (4 waves as 2 x 2) = one 64 x 64 tile of C over one K slice; each wave
+// owns 32 x 32 (2 x 2 MFMA tiles).  Per 32-wide K step the 64 x 32 A tile and the 32 x 64 B tile go global -> registers
+// (issued one step ahead, so their latency hides behind the 32 MFMAs of the current step) -> LDS as As[m][k] / Bs[n][k]
+// (row stride 36 floats: the lanes' 16-byte fragment reads fall on disjoint banks) -> two ds_read_b128 per fragment.
+// AM / BK pick which index runs along the lanes of a load so that the unit (or smaller) stride is the coalesced one.
+// ksplit > 1 (only with accumulate): the K range is cut into slices across workgroups and C is updated with fp32 atomics
+// — weight gradients contract over all B*L stroke rows into a few small tiles, and would otherwise run on a few CUs.
+constexpr int GT = 64, GK = 32, GS = 36;
+
+template <bool AM, bool BK>
+__global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int tiles_n, int ksplit, int kslice) {
+  __shared__ __attribute__((aligned(16))) float As[GT * GS];
+  __shared__ __attribute__((aligned(16))) float Bs[GT * GS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
+  int bx = blockIdx.x;
+  const int ks = bx % ksplit; bx /= ksplit;
+  const int m0 = (bx / tiles_n) * GT, n0 = (bx % tiles_n) * GT;
+  const int z = blockIdx.y, zo = z / g.nzi, zi = z % g.nzi;
+  const float* A = g.A + zo * g.sazo + zi * g.sazi;
+  const float* B = g.B + zo * g.sbzo + zi * g.sbzi;
+  float* C = g.C + zo * g.sczo + zi * g.sczi;
+  const int k_begin = ks * kslice, k_end = min(g.K, k_begin + kslice);
+
+  // staging coordinates of this thread's 8 + 8 elements
+  //   A: AM (m along lanes): m = t & 63, k = (t >> 6) + 4 j;   else (k along lanes): k = t & 31, m = (t >> 5) + 8 j
+  //   B: BK (k along lanes): k = t & 31, n = (t >> 5) + 8 j;   else (n along lanes): n = t & 63, k = (t >> 6) + 4 j
+  float ra[8], rb[8];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
+      const int m = m0 + am, k = k0 + ak;
+      bool ok = m < g.M && k < k_end;
+      long row = m;
+      if (g.a_shift != 0) {
+        const int l = m % g.lr + g.a_shift;
+        ok = ok && l >= 0 && l < g.lr;
+        row = m + g.a_shift;
+      }
+      ra[j] = ok ? A[row * g.sam + (long)k * g.sak] : 0.f;
+      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
+      const int kk = k0 + bk, n = n0 + bn;
+      bool okb = n < g.N && kk < k_end;
+      long krow = kk;
+      if (g.b_shift != 0) {
+        const int l = kk % g.lr + g.b_shift;
+        okb = okb && l >= 0 && l < g.lr;
+        krow = kk + g.b_shift;
+      }
+      rb[j] = okb ? B[krow * g.sbk + (long)n * g.sbn] : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
+      As[am * GS + ak] = ra[j];
+      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
+      Bs[bn * GS + bk] = rb[j];
+    }
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+  if (k_begin < k_end) load(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += GK) {
+    __syncthreads();            // the previous step's fragment reads are done
+    stage();
+    __syncthreads();
+    if (k0 + GK < k_end) load(k0 + GK);
+    Frag<float> fa[2], fb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float* pa = As + (wm + 16 * a + i) * GS + 8 * q;
+      fa[a].lo = *reinterpret_cast<const f32x4*>(pa);
+      fa[a].hi = *reinterpret_cast<const f32x4*>(pa + 4);
+      const float* pb = Bs + (wn + 16 * a + i) * GS + 8 * q;
+      fb[a].lo = *reinterpret_cast<const f32x4*>(pb);
+      fb[a].hi = *reinterpret_cast<const f32x4*>(pb + 4);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
+  }
+
+  // acc[a][b][r] = C[m0 + wm + 16 a + 4 q + r][n0 + wn + 16 b + i]
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int n = n0 + wn + 16 * b + i;
+    if (n >= g.N) continue;
+    const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * a + 4 * q + r;
+        if (m >= g.M) continue;
+        float* c = C + (long)m * g.scm + (long)n * g.scn;
+        const float v = g.alpha * acc[a][b][r] + bias;
+        if (ksplit > 1) atomicAdd(c, v);
+        else *c = g.accumulate ? *c + v : v;
+      }
   }
 }
 
@@ -452,29 +568,57 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(const float* x, const flo
   y[i] = accumulate ? y[i] + v : v;
 }
 // FiLM backward without activation for per-sample [B][C] parameter rows: du (+)= d * gamma, dgamma[b][c] += sum_l d u, dbeta += sum_l d
-__global__ __launch_bounds__(64) void film_bwd2_kernel(const float* d, const float* u, const float* gam, long pstride, int L, int C, float* du, int accumulate,
-                                                        float* dgam, float* dbet) {
-  const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
-  const float ga = gam[b * pstride + c];
+__global__ __launch_bounds__(256) void film_bwd2_kernel(const float* d, const float* u, const float* gam, long pstride, int L, int C, float* du, int accumulate,
+                                                         float* dgam, float* dbet) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, b = blockIdx.y;
   float sg = 0.f, sb = 0.f;
-  for (int l = 0; l < L; ++l) {
-    const long e = ((long)b * L + l) * C + c;
-    const float dd = d[e];
-    sg += dd * u[e];
-    sb += dd;
-    du[e] = accumulate ? du[e] + dd * ga : dd * ga;
+  if (c < C) {
+    const float ga = gam[b * pstride + c];
+    for (int l = rg; l < L; l += 4) {
+      const long e = ((long)b * L + l) * C + c;
+      const float dd = d[e];
+      sg += dd * u[e];
+      sb += dd;
+      du[e] = accumulate ? du[e] + dd * ga : dd * ga;
+    }
   }
-  dgam[b * pstride + c] += sg;
-  dbet[b * pstride + c] += sb;
+  __shared__ float rs[256], rb[256];
+  rs[threadIdx.x] = sg;
+  rb[threadIdx.x] = sb;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const int x = threadIdx.x;
+    dgam[b * pstride + c] += rs[x] + rs[x + 64] + rs[x + 128] + rs[x + 192];
+    dbet[b * pstride + c] += rb[x] + rb[x + 64] + rb[x + 128] + rb[x + 192];
+  }
 }
 
 }  // namespace
 
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1) return hipErrorInvalidValue;
-  const long tiles = (long)((g.M + 15) / 16) * ((g.N + 15) / 16);
-  hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)((tiles + 3) / 4), g.nzo * g.nzi), dim3(256), 0, st, g);
+  static const bool naive = [] { const char* e = getenv("DHW_SGEMM_NAIVE"); return e && *e == '1'; }();
+  if (naive) {
+    const long tiles = (long)((g.M + 15) / 16) * ((g.N + 15) / 16);
+    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)((tiles + 3) / 4), g.nzo * g.nzi), dim3(256), 0, st, g);
+    return hipGetLastError();
+  }
+  const int tiles_m = (g.M + GT - 1) / GT, tiles_n = (g.N + GT - 1) / GT;
+  const long wgs = (long)tiles_m * tiles_n * g.nzo * g.nzi;
+  // split K across workgroups while the tile count leaves most of the 256 CUs idle (accumulating outputs only: atomics)
+  int ksplit = 1;
+  if (g.accumulate && wgs < 512 && g.K >= 8 * GK) ksplit = (int)std::min<long>((512 + wgs - 1) / wgs, g.K / (4 * GK));
+  if (ksplit < 1) ksplit = 1;
+  int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
+  if (g.lr > 0 && g.b_shift != 0 && kslice % GK) return hipErrorInvalidValue;
+  ksplit = (g.K + kslice - 1) / kslice;
+  const dim3 grid((unsigned)(tiles_m * tiles_n * ksplit), g.nzo * g.nzi), block(256);
+  // lanes run along the index whose stride is the smaller one
+  const bool am = std::llabs(g.sam) < std::llabs(g.sak), bk = std::llabs(g.sbk) < std::llabs(g.sbn);
+  if (am && bk) hipLaunchKernelGGL((sgemm_tiled_kernel<true, true>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  else if (am) hipLaunchKernelGGL((sgemm_tiled_kernel<true, false>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  else if (bk) hipLaunchKernelGGL((sgemm_tiled_kernel<false, true>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  else hipLaunchKernelGGL((sgemm_tiled_kernel<false, false>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
   return hipGetLastError();
 }
 hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {
@@ -500,7 +644,7 @@ hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, l
 }
 hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, long pstride, int B, int L, int C, float* du, int accumulate, float* dgam,
                             float* dbet, hipStream_t st) {
-  hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B), dim3(64), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
+  hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B), dim3(256), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
   return hipGetLastError();
 }
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st) {

@@ -79,6 +79,17 @@ class Tape:
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
         self.launches += 1
 
+    def into(self, v: "Var"):
+        """(gradient buffer of v, accumulate flag): the first writer overwrites a fresh buffer, later ones add."""
+        if v.g is not None:
+            return v.g, 1
+        if isinstance(v, _ViewVar):
+            base, _ = self.into(v.base)
+            v.g = base.view(*v.shape)
+        else:
+            v.g = torch.empty_like(v.d)
+        return v.g, 0
+
     def call(self, fn, *args):
         _tcheck(getattr(self.lib, fn)(*args, self.st))
         self.launches += 1
@@ -93,7 +104,8 @@ class Tape:
 
         def bwd():
             dy = y.g
-            self.gemm(dy, 0, N, 1, W.d, 0, K, 1, x.grad(), 0, K, 1, R, K, N, acc=True)          # dx += dy W
+            dx, acc = self.into(x)
+            self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)                 # dx (+)= dy W
             self.gemm(dy, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R, acc=True)          # dW += dy^T x
             if b is not None:
                 self.call("dhw_op_colsum", dy.data_ptr(), R, N, b.grad().data_ptr())
@@ -110,10 +122,11 @@ class Tape:
                       a_shift=t - 1, lr=L)
 
         def bwd():
-            dy, dx, dW = y.g, x.grad(), W.grad()
+            dy, dW = y.g, W.grad()
+            dx, acc = self.into(x)
             for t in range(3):
                 # dx[r] += dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
-                self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=True, a_shift=1 - t, lr=L)
+                self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
                 self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L)
             self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, b.grad().data_ptr())
         self.record(y, bwd)
@@ -124,7 +137,10 @@ class Tape:
         n = x.d.numel()
         self.call("dhw_op_unary", kind, x.d.data_ptr(), n, y.d.data_ptr())
         saved = x.d if kind == 0 else y.d
-        self.record(y, lambda: self.call("dhw_op_unary_bwd", kind, y.g.data_ptr(), saved.data_ptr(), n, x.grad().data_ptr(), 1))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_unary_bwd", kind, y.g.data_ptr(), saved.data_ptr(), n, dx.data_ptr(), acc)
+        self.record(y, bwd)
         return y
 
     def silu(self, x):
@@ -139,8 +155,9 @@ class Tape:
         self.call("dhw_op_add", a.d.data_ptr(), b.d.data_ptr(), n, y.d.data_ptr(), 0)
 
         def bwd():
-            self.call("dhw_op_add", y.g.data_ptr(), None, n, a.grad().data_ptr(), 1)
-            self.call("dhw_op_add", y.g.data_ptr(), None, n, b.grad().data_ptr(), 1)
+            for v in (a, b):
+                dv, acc = self.into(v)
+                self.call("dhw_op_add", y.g.data_ptr(), None, n, dv.data_ptr(), acc)
         self.record(y, bwd)
         return y
 
@@ -148,7 +165,10 @@ class Tape:
         R, Cc = x.d.shape
         y = Var(torch.empty_like(x.d))
         self.call("dhw_op_add_rows", x.d.data_ptr(), table.data_ptr(), B, R // B, Cc, y.d.data_ptr())
-        self.record(y, lambda: self.call("dhw_op_add", y.g.data_ptr(), None, x.d.numel(), x.grad().data_ptr(), 1))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_add", y.g.data_ptr(), None, x.d.numel(), dx.data_ptr(), acc)
+        self.record(y, bwd)
         return y
 
     def film(self, x: Var, gamma: Var, beta: Var, B: int) -> Var:
@@ -157,8 +177,11 @@ class Tape:
         L = R // B
         y = Var(torch.empty_like(x.d))
         self.call("dhw_op_film", x.d.data_ptr(), gamma.d.data_ptr(), beta.d.data_ptr(), Cc, B, L, Cc, y.d.data_ptr())
-        self.record(y, lambda: self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), gamma.d.data_ptr(), Cc, B, L, Cc,
-                                            x.grad().data_ptr(), 1, gamma.grad().data_ptr(), beta.grad().data_ptr()))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), gamma.d.data_ptr(), Cc, B, L, Cc, dx.data_ptr(), acc,
+                      gamma.grad().data_ptr(), beta.grad().data_ptr())
+        self.record(y, bwd)
         return y
 
     def layernorm(self, x: Var) -> Var:
@@ -166,8 +189,10 @@ class Tape:
         y = Var(torch.empty_like(x.d))
         mean, rstd = self.new(R), self.new(R)
         self.call("dhw_op_layernorm", x.d.data_ptr(), R, Cc, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
-        self.record(y, lambda: self.call("dhw_op_layernorm_bwd", y.g.data_ptr(), y.d.data_ptr(), rstd.data_ptr(), R, Cc,
-                                            x.grad().data_ptr(), 1))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_layernorm_bwd", y.g.data_ptr(), y.d.data_ptr(), rstd.data_ptr(), R, Cc, dx.data_ptr(), acc)
+        self.record(y, bwd)
         return y
 
     def resample(self, mode: int, x: Var) -> Var:
@@ -176,7 +201,10 @@ class Tape:
         Ro = R // 2 if mode == 0 else R * 2
         y = Var(self.new(Ro, Cc))
         self.call("dhw_op_resample", mode, x.d.data_ptr(), Ro, Cc, y.d.data_ptr(), 0)
-        self.record(y, lambda: self.call("dhw_op_resample", mode + 1, y.g.data_ptr(), R, Cc, x.grad().data_ptr(), 1))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_resample", mode + 1, y.g.data_ptr(), R, Cc, dx.data_ptr(), acc)
+        self.record(y, bwd)
         return y
 
     def embedding(self, ids: torch.Tensor, table: Var) -> Var:
@@ -205,11 +233,14 @@ class Tape:
         def bwd():
             do = o.g
             dP = S   # the scores are dead after the softmax: reuse their buffer
-            self.gemm(P, 0, 1, Lk, do, 0, HD, 1, v.grad(), 0, HD, 1, Lk, D, Lq, acc=True, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)   # dV += P^T dO
+            dv, av = self.into(v)
+            self.gemm(P, 0, 1, Lk, do, 0, HD, 1, dv, 0, HD, 1, Lk, D, Lq, acc=av, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)          # dV (+)= P^T dO
             self.gemm(do, 0, HD, 1, v.d, 0, 1, HD, dP, 0, Lk, 1, Lq, Lk, D, nzo=B, nzi=H, za=zq, zb=zk, zc=zs)               # dP = dO V^T
             self.call("dhw_op_softmax_bwd", dP.data_ptr(), P.data_ptr(), B * H * Lq, Lk, scale, dP.data_ptr())                # dS (in place)
-            self.gemm(dP, 0, Lk, 1, k.d, 0, HD, 1, q.grad(), 0, HD, 1, Lq, D, Lk, acc=True, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)  # dQ += dS K
-            self.gemm(dP, 0, 1, Lk, q.d, 0, HD, 1, k.grad(), 0, HD, 1, Lk, D, Lq, acc=True, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)  # dK += dS^T Q
+            dq, aq = self.into(q)
+            self.gemm(dP, 0, Lk, 1, k.d, 0, HD, 1, dq, 0, HD, 1, Lq, D, Lk, acc=aq, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)        # dQ (+)= dS K
+            dk, ak = self.into(k)
+            self.gemm(dP, 0, 1, Lk, q.d, 0, HD, 1, dk, 0, HD, 1, Lk, D, Lq, acc=ak, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)        # dK (+)= dS^T Q
         self.record(o, bwd)
         return o
 
@@ -219,7 +250,10 @@ class Tape:
         n = x.d.numel()
         scale = 1.0 / (1.0 - p)
         self.call("dhw_op_mask_mul", x.d.data_ptr(), keep.data_ptr(), scale, n, y.d.data_ptr(), 0)
-        self.record(y, lambda: self.call("dhw_op_mask_mul", y.g.data_ptr(), keep.data_ptr(), scale, n, x.grad().data_ptr(), 1))
+        def bwd():
+            dx, acc = self.into(x)
+            self.call("dhw_op_mask_mul", y.g.data_ptr(), keep.data_ptr(), scale, n, dx.data_ptr(), acc)
+        self.record(y, bwd)
         return y
 
     def backward(self):
@@ -246,23 +280,34 @@ class TrainModel:
         self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.num_layers = num_layers
         self.names = list(state_dict.keys())
-        self.p = {k: Var(torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(self.dev, torch.float32).contiguous())
-                  for k, v in state_dict.items()}
+        host = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).detach().to("cpu", torch.float32).reshape(-1)
+                for k, v in state_dict.items()}
+        shapes = {k: tuple(np.shape(v)) for k, v in state_dict.items()}
+        # ONE flat fp32 buffer for all parameters and one for all gradients (40 MB each): a single memset clears the
+        # gradients, a single kernel pair clips and applies Adam, a single all-reduce averages them across ranks.
+        self.flat = torch.cat([host[k] for k in self.names]).to(self.dev)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.p, off = {}, 0
+        for k in self.names:
+            n = host[k].numel()
+            v = Var(self.flat[off:off + n].view(shapes[k]))
+            v.g = self.flat_grad[off:off + n].view(shapes[k])
+            self.p[k] = v
+            off += n
         self.c1 = self.p["input_dense.weight"].d.shape[0]
         self._pe = {}
         self.tape = None
 
     # ---- parameters ------------------------------------------------------------------------------------------------------
     def parameters(self):
-        return [self.p[k].d for k in self.names]
+        """The flat parameter buffer (every named parameter is a view into it, in state_dict order)."""
+        return [self.flat]
 
     def grads(self):
-        return [self.p[k].grad() for k in self.names]
+        return [self.flat_grad]
 
     def zero_grad(self):
-        for v in self.p.values():
-            if v.g is not None:
-                v.g.zero_()   # hipMemset
+        self.flat_grad.zero_()   # one memset
 
     def state_dict(self):
         return {k: self.p[k].d for k in self.names}
