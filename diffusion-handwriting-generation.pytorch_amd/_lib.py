@@ -83,6 +83,8 @@ SIGNATURES = {
     "dhw_train_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dhw_train_adam": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P, _P]),
+    "dhw_train_adam_dev": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), _P, _P, _P]),
+    "dhw_train_draw": (C.c_int, [_P, C.c_int, C.c_int, _P, _LL, C.c_int, C.c_float, _P, _P]),
     "dhw_train_convblock": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(ConvBlockWeights), _P, _P, _P,
                                       C.POINTER(ConvBlockWeights), _P]),
     "dhw_train_last_error": (C.c_char_p, []),

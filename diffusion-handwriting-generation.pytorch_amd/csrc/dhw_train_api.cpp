@@ -221,6 +221,23 @@ int dhw_train_convblock(int device, int B, int L, int cin, int cout, const float
   return 0;
 }
 
+int dhw_train_adam_dev(int nbuf, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                       const float* hyper, float* sqnorm, void* hip_stream) {
+  if (nbuf < 1 || !p || !g || !m || !v || !n || !hyper || !sqnorm) return tfail(DHW_ERR_ARG, "dhw_train_adam_dev: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  THIP(hipMemsetAsync(sqnorm, 0, sizeof(float), st));
+  for (int i = 0; i < nbuf; ++i) THIP(launch_sqnorm(g[i], n[i], sqnorm, st));
+  for (int i = 0; i < nbuf; ++i) THIP(launch_adam_dev(p[i], g[i], m[i], v[i], n[i], hyper, sqnorm, st));
+  return 0;
+}
+
+int dhw_train_draw(const uint64_t* rng, int B, int L, float* eps, long long n_keep, int keep_per_sample, float p, float* keep, void* hip_stream) {
+  if (!rng || !eps || !keep || B < 1 || L < 1 || n_keep < 1 || keep_per_sample < 4 || keep_per_sample % 4 || n_keep % keep_per_sample || p < 0.f || p >= 1.f)
+    return tfail(DHW_ERR_ARG, "dhw_train_draw: bad argument");
+  THIP(launch_train_draw(rng, B, L, eps, n_keep, keep_per_sample, p, keep, (hipStream_t)hip_stream));
+  return 0;
+}
+
 #define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
 
 int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {

@@ -8,6 +8,7 @@
 
 #include "dhw_common.h"
 #include "dhw_kernels.h"
+#include "heads_core.h"
 
 namespace {
 
@@ -81,6 +82,55 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   m[i] = mi;
   v[i] = vi;
   p[i] -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+// The same update with its scalars read from device memory — hyper = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^t,
+// 1 - beta2^t, max_norm} — so that a captured hipGraph of the whole training step can be replayed with the step's own
+// learning rate and bias corrections (the host rewrites the 8 floats before each replay).
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* sqnorm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
+  float clip = 1.0f;
+  if (max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(*sqnorm) + 1e-6f));
+  const float gi = g[i] * clip + wd * p[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+// The step's random draws on the device (train.py:39 eps = randn_like(x); text_style.py:97 Dropout(0.3) on the style
+// features), from the sampler's counter-based Philox generator: rng = {seed, draw index} in DEVICE memory, so a captured
+// graph draws fresh numbers at every replay once the host has bumped the index.  eps[b][l][:] = normal2(seed,
+// sample = index * B + b, pos = l, iter = 0); the keep-mask uses iter = 1 and one Philox block per 4 elements.
+__global__ __launch_bounds__(256) void train_draw_kernel(const uint64_t* rng, int B, int L, float* eps, long n_keep, int keep_per_sample, float p, float* keep) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t seed = rng[0];
+  const int64_t base = (int64_t)rng[1] * B;
+  if (i < (long)B * L) {
+    float z0, z1;
+    normal2(seed, base + i / L, (int)(i % L), 0, z0, z1);
+    eps[i * 2] = z0;
+    eps[i * 2 + 1] = z1;
+  }
+  if (i * 4 < n_keep) {
+    const long e = i * 4;
+    const int64_t sample = base + e / keep_per_sample;
+    uint32_t c0 = (uint32_t)sample, c1 = (uint32_t)((uint64_t)sample >> 32), c2 = (uint32_t)((e % keep_per_sample) / 4), c3 = 2u;   // iter + 1 = 2
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e + k < n_keep) keep[e + k] = ((float)(c[k] >> 8) + 0.5f) * (1.0f / 16777216.0f) >= p ? 1.0f : 0.0f;
+  }
 }
 
 // a = u * gamma[b] + beta[b];  h = SiLU(a)   (rows C-last [B*L, C]; gamma/beta [B][cols] at column offset)
@@ -227,6 +277,16 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, flo
                        const float* sqnorm, float max_norm, hipStream_t st) {
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(nb(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, sqnorm, max_norm);
+  return hipGetLastError();
+}
+hipError_t launch_train_draw(const uint64_t* rng, int B, int L, float* eps, long n_keep, int keep_per_sample, float p, float* keep, hipStream_t st) {
+  if (keep_per_sample % 4) return hipErrorInvalidValue;
+  const long n = std::max((long)B * L, (n_keep + 3) / 4);
+  hipLaunchKernelGGL(train_draw_kernel, dim3(nb(n)), dim3(256), 0, st, rng, B, L, eps, n_keep, keep_per_sample, p, keep);
+  return hipGetLastError();
+}
+hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* sqnorm, hipStream_t st) {
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(nb(n)), dim3(256), 0, st, p, g, m, v, n, hyper, sqnorm);
   return hipGetLastError();
 }
 hipError_t launch_film_silu_fwd(const float* u, const float* film, long film_bs, int goff, int boff, int B, int L, int C, float* a, float* h, hipStream_t st) {
@@ -607,7 +667,7 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   const long wgs = (long)tiles_m * tiles_n * g.nzo * g.nzi;
   // split K across workgroups while the tile count leaves most of the 256 CUs idle (accumulating outputs only: atomics)
   int ksplit = 1;
-  if (g.accumulate && wgs < 512 && g.K >= 8 * GK) ksplit = (int)std::min<long>((512 + wgs - 1) / wgs, g.K / (4 * GK));
+  if (g.accumulate && wgs < 256 && g.K >= 16 * GK) ksplit = (int)std::min<long>((256 + wgs - 1) / wgs, g.K / (8 * GK));
   if (ksplit < 1) ksplit = 1;
   int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   if (g.lr > 0 && g.b_shift != 0 && kslice % GK) return hipErrorInvalidValue;

@@ -89,6 +89,23 @@ class Adam:
         return gn.sqrt()
 
 
+    def hyper(self, lr: float) -> list:
+        """Advance the update counter and return the 8 scalars ``dhw_train_adam_dev`` reads from device memory."""
+        self.step_count += 1
+        b1, b2 = self.betas
+        return [lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, self.max_norm]
+
+    def step_dev(self, grads, hyper_dev: torch.Tensor, sqnorm_dev: torch.Tensor):
+        """The update with every scalar on the device (``hyper_dev`` = the 8 floats of ``hyper``): no allocation and no
+        host synchronisation, so it can sit inside a captured hipGraph.  ``sqnorm_dev`` receives ||g||^2."""
+        n = len(self.params)
+        dev = self.params[0].device
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        sizes = (C.c_int64 * n)(*[p.numel() for p in self.params])
+        _tcheck(_lib.lib().dhw_train_adam_dev(n, arr(self.params), arr(grads), arr(self.m), arr(self.v), sizes, hyper_dev.data_ptr(),
+                                              sqnorm_dev.data_ptr(), _stream(dev)))
+
+
 def allreduce_grads(flat_grads, world_size: int | None = None):
     """Data-parallel gradient averaging (BASELINE configs[4]: DDP over 8 GPUs): ONE all-reduce of each flat gradient buffer
     (the whole model is 40.1 MB of fp32 gradients — a single bucket per buffer keeps the ring collective bandwidth-bound on

@@ -47,6 +47,17 @@ def positional_encoding(length: int, dim: int, pos_factor: float) -> torch.Tenso
     return torch.cat((e.sin(), e.cos()), dim=-1).float()
 
 
+_SIDE = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One long-lived second stream per device for the parameter-gradient work."""
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
+
+
 class Tape:
     """Forward ops append their backward closure; ``backward()`` replays them in reverse.  Every backward kernel ADDS into
     the input's gradient buffer (zero-initialised on first touch), which is how autograd's fan-in sums arise."""
@@ -54,7 +65,14 @@ class Tape:
     def __init__(self, device):
         self.dev = device
         self.lib = _lib.lib()
+        self.main = torch.cuda.current_stream(device)
         self.st = _stream(device)
+        # parameter gradients (weight-gradient GEMMs, bias sums) are off the critical path of the backward sweep: they run on
+        # a second stream, forked where their upstream gradient becomes ready and joined once at the end of backward()
+        self.side = side_stream(device)
+        self.side_st = C.c_void_p(self.side.cuda_stream)
+        self.forked = False
+        self.held = []
         self.steps = []
         self.launches = 0
 
@@ -62,8 +80,23 @@ class Tape:
     def new(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
 
+    def fork(self, *tensors):
+        """Order the side stream after everything issued so far on the main one; the tensors it will read stay referenced
+        until the join (the allocator must not hand their memory to later main-stream work)."""
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self.forked = True
+        self.held.extend(tensors)
+
+    def join(self):
+        if self.forked:
+            self.main.wait_stream(self.side)
+            self.forked = False
+        self.held = []
+
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
-             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0):
+             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, side=False):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         def extent(off, s0, n0, s1, n1, z):
             return off + (n0 - 1) * s0 + (n1 - 1) * s1 + (nzo - 1) * z[0] + (nzi - 1) * z[1]
@@ -90,8 +123,8 @@ class Tape:
             v.g = torch.empty_like(v.d)
         return v.g, 0
 
-    def call(self, fn, *args):
-        _tcheck(getattr(self.lib, fn)(*args, self.st))
+    def call(self, fn, *args, side=False):
+        _tcheck(getattr(self.lib, fn)(*args, self.side_st if side else self.st))
         self.launches += 1
 
     # ---- differentiable ops ------------------------------------------------------------------------------------------
@@ -106,9 +139,10 @@ class Tape:
             dy = y.g
             dx, acc = self.into(x)
             self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)                 # dx (+)= dy W
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R, acc=True)          # dW += dy^T x
+            self.fork(dy, x.d)
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R, acc=True, side=True)   # dW += dy^T x
             if b is not None:
-                self.call("dhw_op_colsum", dy.data_ptr(), R, N, b.grad().data_ptr())
+                self.call("dhw_op_colsum", dy.data_ptr(), R, N, b.grad().data_ptr(), side=True)
         self.record(y, bwd)
         return y
 
@@ -124,11 +158,12 @@ class Tape:
         def bwd():
             dy, dW = y.g, W.grad()
             dx, acc = self.into(x)
+            self.fork(dy, x.d)
             for t in range(3):
                 # dx[r] += dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
                 self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
-                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L)
-            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, b.grad().data_ptr())
+                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L, side=True)
+            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, b.grad().data_ptr(), side=True)
         self.record(y, bwd)
         return y
 
@@ -260,6 +295,7 @@ class Tape:
         for step in reversed(self.steps):
             step()
         self.steps = []
+        self.join()
 
     def record(self, out: Var, fn):
         """fn runs in the backward sweep iff a gradient reached ``out``."""
@@ -318,6 +354,13 @@ class TrainModel:
             self._pe[key] = positional_encoding(L, dim, factor).to(self.dev)
         return self._pe[key]
 
+    def prepare_tables(self, L: int, Lt: int):
+        """Upload the positional-encoding tables a (L, Lt) batch needs (model.py:40-44) ahead of a graph capture."""
+        c2, c3 = self.p["enc3.text_dense.weight"].d.shape[0], self.p["enc5.text_dense.weight"].d.shape[0]
+        for d, Lx, f in ((c2, L // 2, 4), (c3, L // 4, 2), (2 * c2, L // 8, 1)):
+            self.pe(Lx, d, f)
+            self.pe(Lt, d, 1.0)
+
     # ---- modules ---------------------------------------------------------------------------------------------------------
     def _lin(self, t, x, name):
         return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
@@ -372,23 +415,31 @@ class TrainModel:
         return self._affine(t, t.layernorm(self._ffn(t, tx, n + ".text_ffn")), sigma, n + ".affine4", B)
 
     # ---- forward / backward ----------------------------------------------------------------------------------------------
+    def check_tokens(self, text: torch.Tensor):
+        if text.is_cuda:
+            raise ValueError("token ids are validated on the host: pass a CPU tensor")
+        if int(text.min()) < 0 or int(text.max()) >= self.p["text_style_model.emb.weight"].d.shape[0]:
+            raise ValueError("token id out of the embedding's range")
+
     def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style: torch.Tensor, style_keep: torch.Tensor | None = None):
-        """strokes [B, L, 2], text int64 [B, Lt], sigma [B, 1] (= sqrt(abar), train.py:49), style [B, S, 1280];
+        """strokes [B, L, 2], text int64 [B, Lt] (host), sigma [B, 1] (= sqrt(abar), train.py:49), style [B, S, 1280];
         ``style_keep``: the Dropout(0.3) keep-mask [B, S, 1280] (drawn here when omitted).  -> (score [B, L, 2], pen [B, L])."""
+        dev = self.dev
+        f = lambda a: a.to(dev, torch.float32).contiguous()   # noqa: E731
+        self.check_tokens(text)
+        mask = (text == 0).to(torch.float32).to(dev).contiguous()          # create_padding_mask (utils/nn.py:189), host side
+        if style_keep is None:
+            style_keep = (torch.rand(style.shape) >= self.STYLE_DROP).float()
+        return self.forward_device(f(strokes), text.to(dev, torch.int64).contiguous(), mask, f(sigma), f(style), f(style_keep))
+
+    def forward_device(self, strokes, ids, mask, sigma, style, keep):
+        """``forward`` on device-resident fp32 inputs (ids int64, mask = 1 at padding): kernel launches only."""
         dev = self.dev
         B, L, _ = strokes.shape
         if L % 8:
             raise ValueError("the stroke length must be a multiple of 8 (three AvgPool1d(2) stages)")
         t = self.tape = Tape(dev)
-        f = lambda a: a.to(dev, torch.float32).contiguous()   # noqa: E731
-        ids = text.to(dev, torch.int64).contiguous()
-        if int(text.min()) < 0 or int(text.max()) >= self.p["text_style_model.emb.weight"].d.shape[0]:
-            raise ValueError("token id out of the embedding's range")
-        mask = (text == 0).to(torch.float32).to(dev).contiguous()          # create_padding_mask (utils/nn.py:189), host side
-        if style_keep is None:
-            style_keep = (torch.rand(style.shape) >= self.STYLE_DROP).float()
-        keep = f(style_keep)
-        x_in, sig_in, sty = Var(f(strokes).view(B * L, 2)), Var(f(sigma).view(B, 1)), Var(f(style))
+        x_in, sig_in, sty = Var(strokes.view(B * L, 2)), Var(sigma.view(B, 1)), Var(style)
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
         txt = self._text_style(t, ids, sty, sigma_v, keep, B)                          # [B*Lt, 2 c2]
@@ -455,3 +506,90 @@ def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch
         allreduce_grads(grads)
     model.last_grad_norm = float(optimizer.step(grads, noam_lr(step, d_model, warmup, lr_mul)))   # (one host sync per update)
     return out
+
+
+class GraphedTrainStep:
+    """``train_step`` captured once into a hipGraph and replayed: the ~1300 kernel launches of an update (perturbation,
+    forward, loss, backward, clip + Adam) become one graph launch, which takes the host off the critical path.  The batch
+    lives in static device buffers that each call overwrites; the step's learning rate and Adam bias corrections are 8 floats
+    in device memory rewritten before every replay.  One instance serves one batch shape (B, L, Lt, S)."""
+
+    def __init__(self, model: TrainModel, optimizer: Adam, B: int, L: int, Lt: int, S: int = 14, d_model: int = 256, warmup: int = 10000,
+                 lr_mul: float = 1.0, device_rng: bool = True, seed: int = 0):
+        """``device_rng``: eps and the style Dropout mask are drawn inside the step by the library's Philox generator (as the
+        reference draws them on its device, train.py:39, text_style.py:97); False: the caller passes them (tests)."""
+        dev = model.dev
+        self.device_rng, self.seed = device_rng, seed
+        self.rng = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.model, self.opt = model, optimizer
+        self.shape = (B, L, Lt, S)
+        self.sched = (d_model, warmup, lr_mul)
+        z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+        self.x, self.eps, self.pen, self.alphas = z(B, L, 2), z(B, L, 2), z(B, L), z(B)
+        self.sigma, self.ids, self.mask = z(B, 1), torch.zeros(B, Lt, dtype=torch.int64, device=dev), z(B, Lt)
+        self.style, self.keep = z(B, S, 1280), z(B, S, 1280)
+        self.hyper, self.sqnorm, self.out = z(8), z(1), z(3)
+        model.prepare_tables(L, Lt)
+        self.graph = None
+
+    def _body(self):
+        """Everything of one update that runs on the device (what the graph holds)."""
+        m = self.model
+        B, L = self.shape[:2]
+        x_pert = torch.empty_like(self.x)
+        lib = _lib.lib()
+        st = _stream(m.dev)
+        if self.device_rng:
+            _tcheck(lib.dhw_train_draw(self.rng.data_ptr(), B, L, self.eps.data_ptr(), self.keep.numel(), self.keep.numel() // B,
+                                       TrainModel.STYLE_DROP, self.keep.data_ptr(), st))
+        _tcheck(lib.dhw_train_perturb(self.x.data_ptr(), self.eps.data_ptr(), self.alphas.data_ptr(), B, L, x_pert.data_ptr(), st))
+        m.zero_grad()
+        score, pen_pred = m.forward_device(x_pert, self.ids, self.mask, self.sigma, self.style, self.keep)
+        d_score, d_pen = torch.empty_like(score), torch.empty_like(pen_pred)
+        _tcheck(lib.dhw_train_loss(self.eps.data_ptr(), score.data_ptr(), self.pen.data_ptr(), pen_pred.data_ptr(), self.alphas.data_ptr(), B, L,
+                                   self.out.data_ptr(), d_score.data_ptr(), d_pen.data_ptr(), st))
+        m.backward(d_score, d_pen)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            allreduce_grads(m.grads())
+        self.opt.step_dev(m.grads(), self.hyper, self.sqnorm)
+
+    def __call__(self, batch: dict, alpha_set, step: int, *, eps=None, alphas=None, style_keep=None, graph: bool = True):
+        B, L, Lt, S = self.shape
+        strokes3 = batch["strokes"]
+        if tuple(strokes3.shape) != (B, L, 3) or tuple(batch["text"].shape) != (B, Lt) or tuple(batch["style"].shape) != (B, S, 1280):
+            raise ValueError(f"this step was built for strokes {(B, L, 3)}, text {(B, Lt)}, style {(B, S, 1280)}")
+        self.model.check_tokens(batch["text"])
+        if alphas is None:
+            alphas = get_alphas(B, alpha_set)
+        if self.device_rng:
+            if eps is not None or style_keep is not None:
+                raise ValueError("this step draws eps and the dropout mask on the device (device_rng=True)")
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            world = torch.distributed.get_world_size() if rank or (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+            self.rng.copy_(torch.tensor([self.seed, step * world + rank], dtype=torch.int64))
+        else:
+            self.eps.copy_(eps if eps is not None else torch.randn(B, L, 2))
+            self.keep.copy_(style_keep if style_keep is not None else (torch.rand(B, S, 1280) >= TrainModel.STYLE_DROP).float())
+        self.x.copy_(strokes3[:, :, :2])
+        self.pen.copy_(strokes3[:, :, 2])
+        self.alphas.copy_(alphas.reshape(B))
+        self.sigma.copy_(torch.sqrt(alphas).reshape(B, 1))
+        self.ids.copy_(batch["text"])
+        self.mask.copy_((batch["text"] == 0).float())
+        self.style.copy_(batch["style"])
+        self.hyper.copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched)), dtype=torch.float32))
+        if not graph or (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            self._body()          # (the gradient all-reduce is not captured: multi-rank updates run eagerly)
+        elif self.graph is None:
+            # loss_kernel accumulates into out[1], out[2] — dhw_train_loss zeroes them itself; capture on torch's capture stream
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+            self.graph.replay()
+        else:
+            self.graph.replay()
+        return self.out
+
+    def grad_norm(self) -> float:
+        """||g|| of the last update before clipping (one host synchronisation)."""
+        return float(self.sqnorm.sqrt())

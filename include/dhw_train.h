@@ -38,6 +38,18 @@ int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* cons
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
                    float* grad_norm_out /* device, 1 float, or NULL */, void* hip_stream);
 
+/* The same update with nothing on the host's critical path, for capture into a hipGraph: the scalars come from DEVICE memory
+ * hyper[8] = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^step, 1 - beta2^step, max_norm (<= 0: no clipping)} and the
+ * squared global gradient norm is left in sqnorm (device, 1 float).  No allocation, no synchronisation. */
+int dhw_train_adam_dev(int nbuf, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                       const float* hyper, float* sqnorm, void* hip_stream);
+
+/* The random draws of one update on the device, from the sampler's counter-based Philox generator (dhw.h: the same draw for
+ * any batch sharding): eps ~ N(0,1) [B,L,2] (train.py:39) and the Dropout(p) keep-mask (1 = kept) over n_keep elements,
+ * keep_per_sample of them per batch sample (text_style.py:97: p = 0.3 on [B, S, 1280]).  rng: DEVICE uint64[2] = {seed,
+ * draw index}; sample b of draw d is stream d * B + b, so ranks pass disjoint draw indices.  Capturable. */
+int dhw_train_draw(const uint64_t* rng, int B, int L, float* eps, long long n_keep, int keep_per_sample, float p, float* keep, void* hip_stream);
+
 typedef struct {   /* HOST pointers, torch layouts */
   const float *conv1_w, *conv1_b;   /* [C/2, Cin, 3], [C/2] */
   const float *conv2_w, *conv2_b;   /* [C, C/2, 3], [C] */

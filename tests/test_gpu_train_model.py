@@ -168,7 +168,8 @@ def test_whole_model_gradients_match_the_reference_autograd(golden_dir):
             _close(model.p[k[2:]].g, torch.from_numpy(f[k]), 1e-3)
 
 
-def test_train_steps_follow_the_reference_trajectory(golden_dir):
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_train_steps_follow_the_reference_trajectory(golden_dir, mode):
     """tests/golden/train_traj.npz: four updates of the reference's train_step (train.py:26-67) with its optimizer stack
     (Adam + InvSqrtScheduledOptim + clip_grad_norm_(100), configs/best.yml) on one fixed batch.  The native step — perturb,
     forward, loss, backward, clip, Adam at the Noam rate — must reproduce each step's three losses, the unclipped gradient
@@ -184,13 +185,42 @@ def test_train_steps_follow_the_reference_trajectory(golden_dir):
     eps, alphas = torch.from_numpy(f["eps"]), torch.from_numpy(f["alphas"])
     keeps = np.unpackbits(f["keep"])[:steps * B * S * 1280].reshape(steps, B, S, 1280).astype(np.float32)
     losses = []
+    graphed = tm.GraphedTrainStep(model, opt, B, L, Lt, S, warmup=int(f["warmup"]), device_rng=False) if mode == "graph" else None
     for step in range(1, steps + 1):
-        out = tm.train_step(model, opt, batch, None, step, eps=eps, alphas=alphas, style_keep=torch.from_numpy(keeps[step - 1]),
-                            warmup=int(f["warmup"]))
+        keep = torch.from_numpy(keeps[step - 1])
+        if graphed is not None:      # the hipGraph is captured at step 1 and replayed with new inputs / learning rate afterwards
+            out = graphed(batch, None, step, eps=eps, alphas=alphas, style_keep=keep)
+            norm = graphed.grad_norm()
+        else:
+            out = tm.train_step(model, opt, batch, None, step, eps=eps, alphas=alphas, style_keep=keep, warmup=int(f["warmup"]))
+            norm = model.last_grad_norm
         losses.append(out.cpu().numpy())
-        assert abs(model.last_grad_norm - f["grad_norms"][step - 1]) < 2e-3 * f["grad_norms"][step - 1], (step, model.last_grad_norm)
+        assert abs(norm - f["grad_norms"][step - 1]) < 2e-3 * f["grad_norms"][step - 1], (step, norm)
     losses = np.array(losses)
     print("losses:", losses[:, 0], "reference:", f["losses"][:, 0])
     assert np.allclose(losses, f["losses"], rtol=2e-3), (losses, f["losses"])
     delta = np.array([float((model.p[n].d.cpu() - torch.from_numpy(sd[n])).norm()) for n in model.names])
     assert np.allclose(delta, f["delta"], rtol=2e-2, atol=1e-6), np.abs(delta / np.maximum(f["delta"], 1e-12) - 1).max()
+
+
+def test_device_draws_are_standard_normal_and_drop_30_percent():
+    """dhw_train_draw: eps ~ N(0,1), keep-mask mean 0.7, a new draw index gives new numbers, the same index the same."""
+    import ctypes as C
+    from dhg_amd import _lib
+    B, L, n_keep = 16, 480, 16 * 14 * 1280
+    eps, keep = torch.empty(B, L, 2, device=DEV), torch.empty(n_keep, device=DEV)
+    rng = torch.tensor([7, 3], dtype=torch.int64, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def draw():
+        assert _lib.lib().dhw_train_draw(rng.data_ptr(), B, L, eps.data_ptr(), n_keep, n_keep // B, 0.3, keep.data_ptr(), st) == 0
+        return eps.cpu().clone(), keep.cpu().clone()
+    e1, k1 = draw()
+    e1b, k1b = draw()
+    rng[1] = 4
+    e2, k2 = draw()
+    assert torch.equal(e1, e1b) and torch.equal(k1, k1b) and not torch.equal(e1, e2) and not torch.equal(k1, k2)
+    n = e1.numel()
+    assert abs(float(e1.mean())) < 4 / n ** 0.5 and abs(float(e1.var()) - 1) < 6 * (2 / n) ** 0.5
+    assert set(k1.unique().tolist()) == {0.0, 1.0} and abs(float(k1.mean()) - 0.7) < 4 * (0.21 / n_keep) ** 0.5
+    assert abs(float((k1 * k2).mean()) - 0.49) < 5e-3        # independent across draws
