@@ -223,10 +223,10 @@ hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const 
 
 // generic fp32 ops of the training step (train.hip): see include/dhw_train.h (dhw_op_*)
 struct OpGemm {
-  const float* A; long sam, sak, sazo, sazi; int a_shift;
-  const float* B; long sbk, sbn, sbzo, sbzi; int b_shift;
+  const float* A; long sam, sak, sazo, sazi; int a_shift, a_tap_shift;
+  const float* B; long sbk, sbn, sbzo, sbzi, sbt; int b_shift, b_z_shift;
   float* C; long scm, scn, sczo, sczi;
-  int M, N, K, nzo, nzi, lr;
+  int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate;
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);

@@ -241,13 +241,14 @@ int dhw_train_draw(const uint64_t* rng, int B, int L, float* eps, long long n_ke
 #define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
 
 int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
-  OPCHECK(d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->nzo > 0 && d->nzi > 0 && d->lr >= 0, "dhw_op_gemm");
-  if ((d->a_shift || d->b_shift) && d->lr < 1) return tfail(DHW_ERR_ARG, "dhw_op_gemm: a shift needs lr (rows per sample)");
+  OPCHECK(d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->nzo > 0 && d->nzi > 0 && d->lr >= 0 && d->taps >= 1, "dhw_op_gemm");
+  if ((d->a_shift || d->b_shift || d->a_tap_shift || d->b_z_shift) && d->lr < 1) return tfail(DHW_ERR_ARG, "dhw_op_gemm: a shift needs lr (rows per sample)");
+  if (d->taps > 1 && (d->K % d->taps || (d->K / d->taps) % 32)) return tfail(DHW_ERR_ARG, "dhw_op_gemm: taps > 1 needs K / taps to be a multiple of 32");
   OpGemm g;
-  g.A = d->A; g.sam = d->sam; g.sak = d->sak; g.sazo = d->sazo; g.sazi = d->sazi; g.a_shift = d->a_shift;
-  g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.b_shift = d->b_shift;
+  g.A = d->A; g.sam = d->sam; g.sak = d->sak; g.sazo = d->sazo; g.sazi = d->sazi; g.a_shift = d->a_shift; g.a_tap_shift = d->a_tap_shift;
+  g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.sbt = d->sbt; g.b_shift = d->b_shift; g.b_z_shift = d->b_z_shift;
   g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
-  g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr; g.taps = d->taps;
   g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate;
   THIP(launch_sgemm(g, (hipStream_t)hip_stream));
   return 0;

@@ -335,68 +335,10 @@ hipError_t launch_film_linear_bwd(const float* dfilm, const float* sigma, const 
 namespace {
 
 // C[z][m][n] (+)= alpha * sum_k A(z, m, k) * B(z, k, n) (+ bias[n]);  z = zo * nzi + zi (two batch levels, e.g. sample x head)
-//   A(z,m,k) = A[zo*sazo + zi*sazi + (m + a_shift)*sam + k*sak], zero unless (m mod lr) + a_shift in [0, lr)   (lr = 0: no shift)
-//   B(z,k,n) = B[zo*sbzo + zi*sbzi + (k + b_shift)*sbk + n*sbn], zero unless (k mod lr) + b_shift in [0, lr)
-// One wave = one 16 x 16 tile of C; the K loop steps 32 (8 x v_mfma_f32_16x16x4_f32).
-__global__ __launch_bounds__(256) void sgemm_kernel(const OpGemm g) {
-  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-  const int tiles_n = (g.N + 15) / 16, tiles_m = (g.M + 15) / 16;
-  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= (long)tiles_m * tiles_n) return;
-  const int m0 = (int)(tile / tiles_n) * 16, n0 = (int)(tile % tiles_n) * 16;
-  const int z = blockIdx.y, zo = z / g.nzi, zi = z % g.nzi;
-  const float* A = g.A + zo * g.sazo + zi * g.sazi;
-  const float* B = g.B + zo * g.sbzo + zi * g.sbzi;
-  float* C = g.C + zo * g.sczo + zi * g.sczi;
-  const int m = m0 + i, n = n0 + i;
-  bool a_ok = m < g.M;
-  long a_row = m;
-  if (g.lr > 0 && g.a_shift != 0) {
-    const int l = m % g.lr + g.a_shift;
-    a_ok = a_ok && l >= 0 && l < g.lr;
-    a_row = m + g.a_shift;
-  }
-  const bool b_ok = n < g.N;
-  f32x4 acc = (f32x4){0, 0, 0, 0};
-  for (int k0 = 0; k0 < g.K; k0 += 32) {
-    Frag<float> fa, fb;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + 8 * q + j;
-      float va = 0.f, vb = 0.f;
-      if (k < g.K) {
-        if (a_ok) va = A[a_row * g.sam + (long)k * g.sak];
-        if (b_ok) {
-          bool ok = true;
-          long kr = k;
-          if (g.lr > 0 && g.b_shift != 0) {
-            const int l = k % g.lr + g.b_shift;
-            ok = l >= 0 && l < g.lr;
-            kr = k + g.b_shift;
-          }
-          if (ok) vb = B[kr * g.sbk + (long)n * g.sbn];
-        }
-      }
-      if (j < 4) { fa.lo[j] = va; fb.lo[j] = vb; } else { fa.hi[j - 4] = va; fb.hi[j - 4] = vb; }
-    }
-    mma32(acc, fa, fb);
-  }
-  // acc[r] = C[m0 + 4q + r][n0 + i]
-  if (n0 + i < g.N) {
-    const float bias = g.bias ? g.bias[n0 + i] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mm = m0 + 4 * q + r;
-      if (mm < g.M) {
-        float* c = C + (long)mm * g.scm + (long)(n0 + i) * g.scn;
-        const float v = g.alpha * acc[r] + bias;
-        *c = g.accumulate ? *c + v : v;
-      }
-    }
-  }
-}
-
-// The same contract, LDS-tiled: one workgroup (4 waves as 2 x 2) = one 64 x 64 tile of C over one K slice; each wave
+// with K = taps * Kt and k = tap * Kt + kk (dhw_gemm_desc in include/dhw_train.h):
+//   A(z,m,k) = A[zo*sazo + zi*sazi + (m + sa)*sam + kk*sak],  sa = a_shift + tap*a_tap_shift, zero unless (m mod lr) + sa in [0, lr)
+//   B(z,k,n) = B[zo*sbzo + zi*sbzi + tap*sbt + (kk + sb)*sbk + n*sbn],  sb = b_shift + zi*b_z_shift, zero unless (kk mod lr) + sb in [0, lr)
+// LDS-tiled: one workgroup (4 waves as 2 x 2) = one 64 x 64 tile of C over one K slice; each wave
 // owns 32 x 32 (2 x 2 MFMA tiles).  Per 32-wide K step the 64 x 32 A tile and the 32 x 64 B tile go global -> registers
 // (issued one step ahead, so their latency hides behind the 32 MFMAs of the current step) -> LDS as As[m][k] / Bs[n][k]
 // (row stride 36 floats: the lanes' 16-byte fragment reads fall on disjoint banks) -> two ds_read_b128 per fragment.
@@ -423,29 +365,34 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   //   A: AM (m along lanes): m = t & 63, k = (t >> 6) + 4 j;   else (k along lanes): k = t & 31, m = (t >> 5) + 8 j
   //   B: BK (k along lanes): k = t & 31, n = (t >> 5) + 8 j;   else (n along lanes): n = t & 63, k = (t >> 6) + 4 j
   float ra[8], rb[8];
+  const int Kt = g.K / g.taps;                  // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
+  const int b_sh = g.b_shift + zi * g.b_z_shift;
   auto load = [&](int k0) {
+    const int tap = g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
+    const int a_sh = g.a_shift + tap * g.a_tap_shift;
+    const float* Bt = B + tap * g.sbt;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
-      const int m = m0 + am, k = k0 + ak;
-      bool ok = m < g.M && k < k_end;
+      const int m = m0 + am;
+      bool ok = m < g.M && k0 + ak < k_end;
       long row = m;
-      if (g.a_shift != 0) {
-        const int l = m % g.lr + g.a_shift;
+      if (a_sh != 0) {
+        const int l = m % g.lr + a_sh;
         ok = ok && l >= 0 && l < g.lr;
-        row = m + g.a_shift;
+        row = m + a_sh;
       }
-      ra[j] = ok ? A[row * g.sam + (long)k * g.sak] : 0.f;
+      ra[j] = ok ? A[row * g.sam + (long)(kb + ak) * g.sak] : 0.f;
       const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
-      const int kk = k0 + bk, n = n0 + bn;
-      bool okb = n < g.N && kk < k_end;
+      const int kk = kb + bk, n = n0 + bn;
+      bool okb = n < g.N && k0 + bk < k_end;
       long krow = kk;
-      if (g.b_shift != 0) {
-        const int l = kk % g.lr + g.b_shift;
+      if (b_sh != 0) {
+        const int l = kk % g.lr + b_sh;
         okb = okb && l >= 0 && l < g.lr;
-        krow = kk + g.b_shift;
+        krow = kk + b_sh;
       }
-      rb[j] = okb ? B[krow * g.sbk + (long)n * g.sbn] : 0.f;
+      rb[j] = okb ? Bt[krow * g.sbk + (long)n * g.sbn] : 0.f;
     }
   };
   auto stage = [&]() {
@@ -656,21 +603,15 @@ __global__ __launch_bounds__(256) void film_bwd2_kernel(const float* d, const fl
 }  // namespace
 
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
-  if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1) return hipErrorInvalidValue;
-  static const bool naive = [] { const char* e = getenv("DHW_SGEMM_NAIVE"); return e && *e == '1'; }();
-  if (naive) {
-    const long tiles = (long)((g.M + 15) / 16) * ((g.N + 15) / 16);
-    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)((tiles + 3) / 4), g.nzo * g.nzi), dim3(256), 0, st, g);
-    return hipGetLastError();
-  }
+  if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1 || g.taps < 1) return hipErrorInvalidValue;
+  if (g.taps > 1 && (g.K % g.taps || (g.K / g.taps) % GK)) return hipErrorInvalidValue;
   const int tiles_m = (g.M + GT - 1) / GT, tiles_n = (g.N + GT - 1) / GT;
   const long wgs = (long)tiles_m * tiles_n * g.nzo * g.nzi;
   // split K across workgroups while the tile count leaves most of the 256 CUs idle (accumulating outputs only: atomics)
   int ksplit = 1;
   if (g.accumulate && wgs < 256 && g.K >= 16 * GK) ksplit = (int)std::min<long>((256 + wgs - 1) / wgs, g.K / (8 * GK));
   if (ksplit < 1) ksplit = 1;
-  int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
-  if (g.lr > 0 && g.b_shift != 0 && kslice % GK) return hipErrorInvalidValue;
+  const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;
   const dim3 grid((unsigned)(tiles_m * tiles_n * ksplit), g.nzo * g.nzi), block(256);
   // lanes run along the index whose stride is the smaller one

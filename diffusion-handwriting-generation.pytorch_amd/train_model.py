@@ -96,19 +96,23 @@ class Tape:
         self.held = []
 
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
-             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, side=False):
+             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
-        def extent(off, s0, n0, s1, n1, z):
-            return off + (n0 - 1) * s0 + (n1 - 1) * s1 + (nzo - 1) * z[0] + (nzi - 1) * z[1]
-        if extent(a_off, sam, M, sak, K, za) >= A.numel() or extent(b_off, sbk, K, sbn, N, zb) >= Bm.numel() \
+        Kt = K // taps
+
+        def extent(off, s0, n0, s1, n1, z, tap_stride=0):
+            return off + (n0 - 1) * s0 + (n1 - 1) * s1 + (nzo - 1) * z[0] + (nzi - 1) * z[1] + (taps - 1) * tap_stride
+        if extent(a_off, sam, M, sak, Kt, za) >= A.numel() or extent(b_off, sbk, Kt, sbn, N, zb, sbt) >= Bm.numel() \
                 or extent(c_off, scm, M, scn, N, zc) >= Cm.numel() or min(a_off, b_off, c_off) < 0:
             raise ValueError("gemm operand extents exceed their buffers")
-        if (a_shift or b_shift) and (lr < 1 or (M if a_shift else K) % lr):
-            raise ValueError("shifted gemm needs whole samples of lr rows")
-        d = _lib.GemmDesc(A.data_ptr() + a_off * _F, sam, sak, za[0], za[1], a_shift,
-                          Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], b_shift,
+        if (a_shift or a_tap_shift) and (lr < 1 or M % lr):
+            raise ValueError("a row-shifted gemm needs whole samples of lr rows")
+        if (b_shift or b_z_shift) and (lr < 1 or Kt % lr):
+            raise ValueError("a row-shifted gemm needs whole samples of lr rows")
+        d = _lib.GemmDesc(A.data_ptr() + a_off * _F, sam, sak, za[0], za[1], a_shift, a_tap_shift,
+                          Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
-                          M, N, K, nzo, nzi, lr, bias.data_ptr() if bias is not None else None, alpha, int(acc))
+                          M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc))
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
         self.launches += 1
 
@@ -139,10 +143,11 @@ class Tape:
             dy = y.g
             dx, acc = self.into(x)
             self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)                 # dx (+)= dy W
+            dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
             self.fork(dy, x.d)
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R, acc=True, side=True)   # dW += dy^T x
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, side=True)         # dW += dy^T x
             if b is not None:
-                self.call("dhw_op_colsum", dy.data_ptr(), R, N, b.grad().data_ptr(), side=True)
+                self.call("dhw_op_colsum", dy.data_ptr(), R, N, db.data_ptr(), side=True)
         self.record(y, bwd)
         return y
 
@@ -151,19 +156,30 @@ class Tape:
         R, Cin = x.d.shape
         Cout = W.d.shape[0]
         y = Var(self.new(R, Cout))
-        for t in range(3):
-            self.gemm(x.d, 0, Cin, 1, W.d, t, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
-                      a_shift=t - 1, lr=L)
+        merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
+        if merged:
+            self.gemm(x.d, 0, Cin, 1, W.d, 0, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
+                      sbt=1, lr=L)
+        else:
+            for t in range(3):
+                self.gemm(x.d, 0, Cin, 1, W.d, t, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
+                          a_shift=t - 1, lr=L)
 
         def bwd():
-            dy, dW = y.g, W.grad()
+            dy, dW, db = y.g, W.grad(), b.grad()
             dx, acc = self.into(x)
             self.fork(dy, x.d)
-            for t in range(3):
-                # dx[r] += dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
-                self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
-                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L, side=True)
-            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, b.grad().data_ptr(), side=True)
+            # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
+            if merged:
+                self.gemm(dy, 0, Cout, 1, W.d, 0, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
+                          sbt=1, lr=L)
+                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, Cin * 3, 3, Cout, Cin, R, acc=True, nzi=3, zc=(0, 1), b_shift=-1,
+                          b_z_shift=1, lr=L, side=True)                                       # the taps as the inner batch index
+            else:
+                for t in range(3):
+                    self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
+                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L, side=True)
+            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, db.data_ptr(), side=True)
         self.record(y, bwd)
         return y
 

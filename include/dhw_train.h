@@ -74,15 +74,19 @@ int dhw_train_convblock(int device, int B, int L, int cin, int cout, const float
  * the GEMM takes strides).  `accumulate` != 0 adds into the destination (gradient fan-in) instead of overwriting it. */
 
 typedef struct {
-  /* C[z][m][n] (+)= alpha * sum_k A(z,m,k) B(z,k,n) (+ bias[n]);  z = zo * nzi + zi  (two batch levels, e.g. sample x head)
-   *   A(z,m,k) = A[zo*sazo + zi*sazi + (m + a_shift)*sam + k*sak], taken as 0 unless (m mod lr) + a_shift is in [0, lr)
-   *   B(z,k,n) = B[zo*sbzo + zi*sbzi + (k + b_shift)*sbk + n*sbn], taken as 0 unless (k mod lr) + b_shift is in [0, lr)
+  /* C[z][m][n] (+)= alpha * sum_k A(z,m,k) B(z,k,n) (+ bias[n]);  z = zo * nzi + zi  (two batch levels, e.g. sample x head),
+   * K = taps * Kt and k = tap * Kt + kk  (taps = 1: plain GEMM; taps = 3: the three Conv1d taps in one contraction):
+   *   A(z,m,k) = A[zo*sazo + zi*sazi + (m + sa)*sam + kk*sak],  sa = a_shift + tap*a_tap_shift,
+   *              taken as 0 unless (m mod lr) + sa is in [0, lr)
+   *   B(z,k,n) = B[zo*sbzo + zi*sbzi + tap*sbt + (kk + sb)*sbk + n*sbn],  sb = b_shift + zi*b_z_shift,
+   *              taken as 0 unless (kk mod lr) + sb is in [0, lr)
    * lr = rows per sample for the Conv1d taps ('same' zero padding inside each sample; 0 = no shifting).  One description
-   * covers nn.Linear / Conv1d forward, data gradient and weight gradient and the per-head attention products. */
-  const float* A; long long sam, sak, sazo, sazi; int a_shift;
-  const float* B; long long sbk, sbn, sbzo, sbzi; int b_shift;
+   * covers nn.Linear / Conv1d forward, data gradient and weight gradient and the per-head attention products.
+   * taps > 1 needs Kt to be a multiple of 32. */
+  const float* A; long long sam, sak, sazo, sazi; int a_shift, a_tap_shift;
+  const float* B; long long sbk, sbn, sbzo, sbzi, sbt; int b_shift, b_z_shift;
   float* C; long long scm, scn, sczo, sczi;
-  int M, N, K, nzo, nzi, lr;
+  int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate;
 } dhw_gemm_desc;
 

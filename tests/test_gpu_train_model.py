@@ -48,17 +48,19 @@ def _run(build, inputs, dout_seed=9):
 
 def test_linear_and_conv3_in_all_three_directions():
     g = torch.Generator().manual_seed(1)
-    B, L, Cin, Cout = 3, 20, 40, 72          # not multiples of 16 / 32: the GEMM's edge masking
-    x = torch.randn(B * L, Cin, generator=g, requires_grad=True)
-    W = torch.randn(Cout, Cin, 3, generator=g, requires_grad=True)
-    b = torch.randn(Cout, generator=g, requires_grad=True)
-    y, (vx, vW, vb), dy = _run(lambda t, x, W, b: t.conv3(x, W, b, L), (x, W, b))
-    ref = F.conv1d(x.view(B, L, Cin).transpose(1, 2), W, b, padding="same").transpose(1, 2).reshape(B * L, Cout)
-    ref.backward(dy)
-    _close(y.d, ref)
-    _close(vx.g, x.grad)
-    _close(vW.g, W.grad)
-    _close(vb.g, b.grad)
+    # (40, 72): not multiples of 16 / 32 — the GEMM's edge masking, one launch per tap; (64, 96): the three taps merged into
+    # one contraction (dhw_gemm_desc.taps) and, for the weight gradient, into the batch index
+    for B, L, Cin, Cout in ((3, 20, 40, 72), (2, 24, 64, 96)):
+        x = torch.randn(B * L, Cin, generator=g, requires_grad=True)
+        W = torch.randn(Cout, Cin, 3, generator=g, requires_grad=True)
+        b = torch.randn(Cout, generator=g, requires_grad=True)
+        y, (vx, vW, vb), dy = _run(lambda t, x, W, b: t.conv3(x, W, b, L), (x, W, b))
+        ref = F.conv1d(x.view(B, L, Cin).transpose(1, 2), W, b, padding="same").transpose(1, 2).reshape(B * L, Cout)
+        ref.backward(dy)
+        _close(y.d, ref)
+        _close(vx.g, x.grad)
+        _close(vW.g, W.grad)
+        _close(vb.g, b.grad)
 
     x = torch.randn(50, 2, generator=g, requires_grad=True)                    # K = 2: input_dense
     W = torch.randn(130, 2, generator=g, requires_grad=True)
