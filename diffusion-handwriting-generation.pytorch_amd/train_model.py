@@ -525,8 +525,9 @@ def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch
 
 
 class GraphedTrainStep:
-    """``train_step`` captured once into a hipGraph and replayed: the ~1300 kernel launches of an update (perturbation,
-    forward, loss, backward, clip + Adam) become one graph launch, which takes the host off the critical path.  The batch
+    """``train_step`` with its gradient computation captured once into a hipGraph and replayed: the ~1100 kernel launches of
+    an update (draws, perturbation, forward, loss, backward) become one graph launch, which takes the host off the critical
+    path; the gradient all-reduce (multi-rank) and clip + Adam follow as three eager launches.  The batch
     lives in static device buffers that each call overwrites; the step's learning rate and Adam bias corrections are 8 floats
     in device memory rewritten before every replay.  One instance serves one batch shape (B, L, Lt, S)."""
 
@@ -565,6 +566,11 @@ class GraphedTrainStep:
         _tcheck(lib.dhw_train_loss(self.eps.data_ptr(), score.data_ptr(), self.pen.data_ptr(), pen_pred.data_ptr(), self.alphas.data_ptr(), B, L,
                                    self.out.data_ptr(), d_score.data_ptr(), d_pen.data_ptr(), st))
         m.backward(d_score, d_pen)
+
+    def _apply(self):
+        """Gradient averaging across ranks (one all-reduce of the flat 40 MB buffer: RCCL over xGMI) and the optimizer: three
+        launches, issued eagerly after the graph so that the collective stays outside the capture."""
+        m = self.model
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             allreduce_grads(m.grads())
         self.opt.step_dev(m.grads(), self.hyper, self.sqnorm)
@@ -594,8 +600,8 @@ class GraphedTrainStep:
         self.mask.copy_((batch["text"] == 0).float())
         self.style.copy_(batch["style"])
         self.hyper.copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched)), dtype=torch.float32))
-        if not graph or (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
-            self._body()          # (the gradient all-reduce is not captured: multi-rank updates run eagerly)
+        if not graph:
+            self._body()
         elif self.graph is None:
             # loss_kernel accumulates into out[1], out[2] — dhw_train_loss zeroes them itself; capture on torch's capture stream
             self.graph = torch.cuda.CUDAGraph()
@@ -604,6 +610,7 @@ class GraphedTrainStep:
             self.graph.replay()
         else:
             self.graph.replay()
+        self._apply()
         return self.out
 
     def grad_norm(self) -> float:

@@ -226,3 +226,37 @@ def test_device_draws_are_standard_normal_and_drop_30_percent():
     assert abs(float(e1.mean())) < 4 / n ** 0.5 and abs(float(e1.var()) - 1) < 6 * (2 / n) ** 0.5
     assert set(k1.unique().tolist()) == {0.0, 1.0} and abs(float(k1.mean()) - 0.7) < 4 * (0.21 / n_keep) ** 0.5
     assert abs(float((k1 * k2).mean()) - 0.49) < 5e-3        # independent across draws
+
+
+def test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch(tmp_path):
+    """Data parallelism of the training step (BASELINE configs[4]): two ranks, each with half of a seeded batch, averaging their
+    flat gradient buffers through ``allreduce_grads`` (gloo here: both ranks share the box's one GPU; RCCL on a real node), must
+    land on the parameters one rank reaches with the whole batch — the losses are batch means, so the mean of the two ranks'
+    gradients IS the whole-batch gradient."""
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "ddp_worker.py")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    single = subprocess.run([sys.executable, worker, "0", "1", port, str(tmp_path / "w1.npz")], env=env, timeout=300)
+    assert single.returncode == 0
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path / "w2.npz")], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz")
+    # rank 0 of the pair reports the loss of ITS half; the parameters are what must agree
+    assert np.isfinite(b["losses"]).all()
+    # Adam's early updates are ~ lr * g / (|g| + 1e-8): elements whose gradient is at rounding level move by a
+    # summation-order-dependent amount, so the comparison is in the L2 norm of the whole displacement
+    diff = np.linalg.norm((a["flat"] - b["flat"]).astype(np.float64))
+    moved = np.linalg.norm((a["flat"] - spec_flat()).astype(np.float64))
+    print("parameter difference 2 ranks vs 1 (L2):", diff, "displacement (L2):", moved)
+    assert moved > 1e-3 and diff < 1e-3 * moved
+
+
+def spec_flat():
+    sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    return np.concatenate([np.asarray(v, np.float32).ravel() for v in sd.values()])
