@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA (v_mfma_f32_16x16x4_f32) = the f32 vector rate (MI355X_MICROARCH.md)
 
 
 def parse_args(argv=None):
@@ -43,9 +44,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="prompts per GPU")
-    ap.add_argument("--L", type=int, default=488)
-    ap.add_argument("--Lt", type=int, default=30)
+    ap.add_argument("--train", action="store_true",
+                    help="time the training step instead (BASELINE configs[4]: forward + loss + backward + all-reduce + Adam; "
+                         "batch 32/GPU, L=480, Lt=50, fp32) — a second metric, not the headline line")
+    ap.add_argument("--batch", type=int, default=None, help="prompts per GPU (default 64; 32 with --train)")
+    ap.add_argument("--L", type=int, default=None, help="stroke length (default 488; 480 with --train)")
+    ap.add_argument("--Lt", type=int, default=None, help="text length (default 30; 50 with --train)")
     ap.add_argument("--T", type=int, default=60)
     ap.add_argument("--num-layers", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -60,7 +64,11 @@ def parse_args(argv=None):
                          "for the barrier (RCCL refuses two ranks on one device); the line is marked, never a scaling result")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    a.batch = a.batch or (32 if a.train else 64)
+    a.L = a.L or (480 if a.train else 488)
+    a.Lt = a.Lt or (50 if a.train else 30)
+    return a
 
 
 # ---------------------------------------------------------------------------------------------- launcher (parent)
@@ -140,6 +148,8 @@ def worker(args):
             dist.init_process_group("nccl", device_id=dev)
 
     B, L, Lt, T = args.batch, args.L, args.Lt, args.T
+    if args.train and not args.stub:
+        return train_worker(args, dev, dist, rank, world)
     if args.stub:
         if rank == args.stub_fail_rank:
             raise SystemExit(3)
@@ -247,6 +257,116 @@ def worker(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_worker(args, dev, dist, rank, world):
+    """--train: K updates of the native training step (dhg_amd.train_model.GraphedTrainStep) on one synthetic batch per
+    rank; N > 1 averages the flat gradient buffer with one RCCL all-reduce per update (data parallel, weak scaling)."""
+    import numpy as np
+    import torch
+    from dhg_amd import spec, train, train_model as tm
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    B, L, Lt = args.batch, args.L, args.Lt
+    sd = spec.synthetic_state_dict(args.num_layers, 128, 192, 256, seed=0)
+    model = tm.TrainModel(sd, num_layers=args.num_layers, device=dev)
+    opt = train.Adam(model.parameters())
+    inp = spec.synthetic_inputs_range(rank * B, B, L, Lt, seed=3, T=0)
+    g = torch.Generator().manual_seed(3 + rank)
+    strokes = torch.randn(B, L, 2, generator=g)
+    batch = {"strokes": torch.cat([strokes, (torch.rand(B, L, 1, generator=g) < 0.1).float()], dim=-1),
+             "text": torch.from_numpy(inp["text"]), "style": torch.from_numpy(inp["style"])}
+    alpha_set = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "sched.npz"))["alpha"])
+    step_fn = tm.GraphedTrainStep(model, opt, B, L, Lt)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    losses = []
+    for k in range(args.warmup):
+        losses.append(step_fn(batch, alpha_set, k + 1, graph=not args.no_graph).clone())
+        sync()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        losses.append(step_fn(batch, alpha_set, args.warmup + k + 1, graph=not args.no_graph).clone())
+    sync()
+    dt_own = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt_own]
+    if dist is not None:
+        cdev = torch.device("cpu") if args.share_gpu else dev
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        own = [torch.zeros(1, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(own, torch.tensor([dt_own], device=cdev, dtype=torch.float64))
+        per_rank = [float(x.item()) for x in own]
+    lv = [float(x[0]) for x in losses]
+    assert all(np.isfinite(lv)), "non-finite loss"
+    value = world * B * args.steps / dt
+    gemm_tflops = model.last_gemm_flops * args.steps / dt_own / 1e12
+    res = {"metric": "training samples/sec (forward + loss + backward + grad all-reduce + clip + Adam; L=480)", "value": value,
+           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"configs[4]: training step, batch={B}/GPU, L={L}, Lt={Lt}, d_model=128/192/256, num_layers={args.num_layers}, "
+                                  "dropout 0.0 + style Dropout(0.3), Adam + Noam + clip 100, random-init weights",
+                      "global_batch": world * B, "seq_len": L,
+                      "parallelism": f"data-parallel x{world}" + (" (one all-reduce of the flat 40 MB gradient buffer per update)" if world > 1 else "")},
+           "per_rank_ms": [t / args.steps * 1e3 for t in per_rank], "loss_first_last": [lv[0], lv[-1]],
+           "launches_per_update": model.last_launches, "launch": "eager" if args.no_graph else "hipGraph",
+           "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_F32_TFLOPS,
+                        "traffic": None, "kernel": "whole update (all GEMM FLOPs / wall time of the update)",
+                        "gemm_flops_per_update": model.last_gemm_flops}}
+    if args.share_gpu:
+        res["data"] = "synthetic; REHEARSAL: ranks share GPUs (not a scaling measurement)"
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_train_baseline(args, spec)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_train_baseline(args, spec):
+    """The oracle's forward (oracle/ref_cpu.py, the CPU restatement of the reference) under torch autograd with the reference's
+    loss — forward + backward of a small batch at the same L on this box's host cores (the optimizer is left out: it is
+    <1 % of a CPU step).  kind "port"."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import ref_cpu
+    B, L, Lt = 16, args.L, args.Lt
+    cores = torch.get_num_threads()
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in spec.synthetic_state_dict(args.num_layers).items()}
+    inp = spec.synthetic_inputs_range(0, B, L, Lt, seed=3, T=0)
+    g = torch.Generator().manual_seed(1)
+    x, eps = torch.randn(B, L, 2, generator=g), torch.randn(B, L, 2, generator=g)
+    pen = (torch.rand(B, L, generator=g) < 0.1).float()
+    alphas = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+
+    def step():
+        xp = torch.sqrt(alphas).unsqueeze(-1) * x + torch.sqrt(1 - alphas).unsqueeze(-1) * eps
+        out = ref_cpu.forward(sd, xp, torch.from_numpy(inp["text"]), torch.sqrt(alphas), torch.from_numpy(inp["style"]))
+        score, pp = out[0], out[1]
+        loss = ((eps - score) ** 2).sum(-1).mean() + (F.binary_cross_entropy(pp, pen.clamp(1e-7, 1 - 1e-7), reduction="none").mean(-1) * alphas.squeeze(-1)).mean()
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+    step()
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        best = min(best, time.perf_counter() - t0)
+    return {"value": B / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"forward + loss + backward of {B} samples (L={L}, Lt={Lt}) through the CPU oracle under torch autograd, best of 3"}
 
 
 def kernel_profile(model, one_step):

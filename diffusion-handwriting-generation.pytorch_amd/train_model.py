@@ -75,6 +75,7 @@ class Tape:
         self.held = []
         self.steps = []
         self.launches = 0
+        self.flops = 0          # algorithmic FLOPs of every GEMM issued (2 M N K per batch entry)
 
     # ---- raw kernel wrappers ---------------------------------------------------------------------------------------
     def new(self, *shape) -> torch.Tensor:
@@ -481,6 +482,7 @@ class TrainModel:
         self._score.g = d_score.contiguous().view_as(self._score.d)
         self._pen.g = d_pen.contiguous().view_as(self._pen.d)
         self.tape.backward()
+        self.last_launches, self.last_gemm_flops = self.tape.launches, self.tape.flops
         self.tape = None
 
 
