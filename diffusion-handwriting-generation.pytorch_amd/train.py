@@ -1,10 +1,10 @@
-"""First slice of the training step (BASELINE configs[4]; reference train.py:26-67).
+"""Pieces of the training step (BASELINE configs[4]; reference train.py:26-67).
 
-What runs natively (HIP, include/dhw_train.h): the forward-diffusion perturbation, ``loss_fn`` with its gradient, global
-gradient-norm clipping + Adam on flat buffers, and ConvBlock forward + backward.  Host logic mirrored here: ``get_alphas``
-(the reference's torch RNG calls, in its order), the Noam learning-rate schedule, and the data-parallel gradient
-all-reduce (``torch.distributed``: RCCL over xGMI on the GPU ranks).  NOT built yet: the backward kernels of the
-EncoderLayers and of the TextStyleEncoder, so ``DiffusionModel`` cannot be trained end to end natively — DESIGN.md §9.
+HIP (include/dhw_train.h): the forward-diffusion perturbation, ``loss_fn`` with its gradient, global gradient-norm clipping +
+Adam on flat buffers, ConvBlock forward + backward as one call.  Host logic mirrored here: ``get_alphas`` (the reference's
+torch RNG calls, in its order), the Noam learning-rate schedule, and the data-parallel gradient all-reduce
+(``torch.distributed``: RCCL over xGMI on the GPU ranks).  The whole model's forward / backward and the complete update
+are in ``train_model.py``.
 """
 from __future__ import annotations
 

@@ -67,8 +67,10 @@ class Tape:
         self.lib = _lib.lib()
         self.main = torch.cuda.current_stream(device)
         self.st = _stream(device)
-        # parameter gradients (weight-gradient GEMMs, bias sums) are off the critical path of the backward sweep: they run on
-        # a second stream, forked where their upstream gradient becomes ready and joined once at the end of backward()
+        # bias-gradient sums are off the critical path of the backward sweep: they run on a second stream, forked where their
+        # upstream gradient becomes ready and joined once at the end of backward().  (The weight-gradient GEMMs stay on the main
+        # stream: run beside the data-gradient chain they slowed the update from 15.1 to 17.3 ms — two GEMMs sharing the CUs
+        # lose more to L2 / LDS contention than the idle CUs of the small ones gain.)
         self.side = side_stream(device)
         self.side_st = C.c_void_p(self.side.cuda_stream)
         self.forked = False
@@ -114,8 +116,9 @@ class Tape:
                           Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc))
-        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
+        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
+        self.flops += 2 * M * N * K * nzo * nzi
 
     def into(self, v: "Var"):
         """(gradient buffer of v, accumulate flag): the first writer overwrites a fresh buffer, later ones add."""
@@ -146,7 +149,7 @@ class Tape:
             self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)                 # dx (+)= dy W
             dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
             self.fork(dy, x.d)
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, side=True)         # dW += dy^T x
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True)         # dW += dy^T x
             if b is not None:
                 self.call("dhw_op_colsum", dy.data_ptr(), R, N, db.data_ptr(), side=True)
         self.record(y, bwd)
@@ -175,11 +178,11 @@ class Tape:
                 self.gemm(dy, 0, Cout, 1, W.d, 0, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
                           sbt=1, lr=L)
                 self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, Cin * 3, 3, Cout, Cin, R, acc=True, nzi=3, zc=(0, 1), b_shift=-1,
-                          b_z_shift=1, lr=L, side=True)                                       # the taps as the inner batch index
+                          b_z_shift=1, lr=L)                                       # the taps as the inner batch index
             else:
                 for t in range(3):
                     self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
-                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L, side=True)
+                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L)
             self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, db.data_ptr(), side=True)
         self.record(y, bwd)
         return y
