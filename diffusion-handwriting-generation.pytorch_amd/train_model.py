@@ -6,7 +6,7 @@
 FiLM, LayerNorm, softmax, resampling, embedding and activation kernels).  torch supplies device memory and streams only:
 no torch operator touches an activation or a gradient.  The op order mirrors the reference module by module so that the
 recorded tape, replayed in reverse, accumulates exactly autograd's gradients; ``tests/test_gpu_train.py`` pins every one
-of the 323 parameter gradients against a fixture the imported reference generated (oracle/make_golden_r2.py).
+of the 323 parameter gradients against a fixture the imported reference generated (tests/golden/model_grad.npz).
 
 Parameters keep the reference's ``state_dict`` names and torch layouts, so a reference checkpoint loads unchanged and a
 trained one can be handed straight to ``dhg_amd.DiffusionModel`` for sampling.
