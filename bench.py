@@ -401,13 +401,15 @@ def kernel_profile(model, one_step):
 
 
 def kernel_source_hash() -> str:
-    """Hash of the kernel sources the library is built from (the GPU box has no .git, so a commit id is not available
-    there): the PMC file records the hash it was taken at, and a mismatch marks the traffic figure stale."""
+    """Hash of the sampling path's kernel sources (the GPU box has no .git, so a commit id is not available there): the PMC
+    file records the hash it was taken at, and a mismatch marks the traffic figure stale.  The StyleExtractor and training
+    sources are left out: they do not change what the sampler's kernels fetch."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd", "csrc")
+    other = {"train.hip", "style.hip", "dhw_train_api.cpp", "dhw_style_api.cpp"}
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) and f not in other:
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
