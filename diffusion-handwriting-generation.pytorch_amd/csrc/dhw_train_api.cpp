@@ -238,6 +238,13 @@ int dhw_train_draw(const uint64_t* rng, int B, int L, float* eps, long long n_ke
   return 0;
 }
 
+int dhw_op_keep_mask(const uint64_t* rng, int site, long long n, int per_sample, float p, float* keep, void* hip_stream) {
+  if (!rng || !keep || site < 3 || n < 1 || per_sample < 4 || per_sample % 4 || n % per_sample || p < 0.f || p >= 1.f)
+    return tfail(DHW_ERR_ARG, "dhw_op_keep_mask: bad argument");
+  THIP(launch_keep_mask(rng, site, n, per_sample, p, keep, (hipStream_t)hip_stream));
+  return 0;
+}
+
 #define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
 
 int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {

@@ -133,6 +133,28 @@ __global__ __launch_bounds__(256) void train_draw_kernel(const uint64_t* rng, in
   }
 }
 
+// A Dropout(p) keep-mask (1 = kept) over n elements, per_sample of them per batch sample, from the same generator:
+// Philox block (sample = index * B + b, element / 4, site) — `site` >= 3 numbers the model's dropout sites (1 = eps, 2 = the
+// style mask of train_draw_kernel), so every site of every update draws an independent mask.
+__global__ __launch_bounds__(256) void keep_mask_kernel(const uint64_t* rng, uint32_t site, long n, int per_sample, float p, float* keep) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  const uint64_t seed = rng[0];
+  const int64_t sample = (int64_t)rng[1] * (n / per_sample) + e / per_sample;
+  uint32_t c0 = (uint32_t)sample, c1 = (uint32_t)((uint64_t)sample >> 32), c2 = (uint32_t)((e % per_sample) / 4), c3 = site;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (e + k < n) keep[e + k] = ((float)(c[k] >> 8) + 0.5f) * (1.0f / 16777216.0f) >= p ? 1.0f : 0.0f;
+}
+
 // a = u * gamma[b] + beta[b];  h = SiLU(a)   (rows C-last [B*L, C]; gamma/beta [B][cols] at column offset)
 __global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* u, const float* film, long film_bs, int goff, int boff, int L, int C,
                                                              long n4, float* a_out, float* h_out) {
@@ -283,6 +305,11 @@ hipError_t launch_train_draw(const uint64_t* rng, int B, int L, float* eps, long
   if (keep_per_sample % 4) return hipErrorInvalidValue;
   const long n = std::max((long)B * L, (n_keep + 3) / 4);
   hipLaunchKernelGGL(train_draw_kernel, dim3(nb(n)), dim3(256), 0, st, rng, B, L, eps, n_keep, keep_per_sample, p, keep);
+  return hipGetLastError();
+}
+hipError_t launch_keep_mask(const uint64_t* rng, int site, long n, int per_sample, float p, float* keep, hipStream_t st) {
+  if (per_sample % 4 || n % per_sample || site < 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(nb((n + 3) / 4)), dim3(256), 0, st, rng, (uint32_t)site, n, per_sample, p, keep);
   return hipGetLastError();
 }
 hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* sqnorm, hipStream_t st) {

@@ -327,14 +327,18 @@ class TrainModel:
 
     STYLE_DROP = 0.3   # text_style.py:88
 
-    def __init__(self, state_dict: dict, num_layers: int = 2, device=None, drop_rate: float = 0.0):
-        if drop_rate != 0.0:
-            # configs/best.yml trains with dropout 0.0; only the TextStyleEncoder's fixed Dropout(0.3) is active
-            raise NotImplementedError("EncoderLayer dropout > 0 is not built; the reference's training config uses 0.0")
+    def __init__(self, state_dict: dict, num_layers: int = 2, device=None, drop_rate: float = 0.0, seed: int = 0):
+        """``drop_rate``: the EncoderLayers' dropout (model.py:23; configs/best.yml trains with 0.0, the class default is 0.1)."""
+        if not 0.0 <= drop_rate < 1.0:
+            raise ValueError("drop_rate must be in [0, 1)")
         if not torch.cuda.is_available():
             raise RuntimeError("TrainModel needs the MI355X: the training step has no CPU path")
         self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.num_layers = num_layers
+        self.num_layers, self.drop_rate = num_layers, float(drop_rate)
+        # {seed, draw index} of the device generator behind the dropout masks (and GraphedTrainStep's eps draw)
+        self.seed = seed
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=self.dev)
+        self._masks, self._site = None, 3
         self.names = list(state_dict.keys())
         host = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).detach().to("cpu", torch.float32).reshape(-1)
                 for k, v in state_dict.items()}
@@ -405,19 +409,32 @@ class TrainModel:
         h = self._affine(t, self._lin(t, t.silu(h), name + ".fc"), sigma, name + ".affine3", B)
         return t.add(h, skip)
 
+    def _drop(self, t, v, B):
+        """EncoderLayer.drop (model.py:23): identity at rate 0; otherwise the next caller-supplied keep-mask (parity tests) or a
+        mask drawn on the device for this site of this update."""
+        if self.drop_rate == 0.0:
+            return v
+        if self._masks is not None:
+            keep = next(self._masks).to(self.dev, torch.float32).contiguous().view_as(v.d)
+        else:
+            keep = torch.empty_like(v.d)
+            t.call("dhw_op_keep_mask", self.rng.data_ptr(), self._site, v.d.numel(), v.d.numel() // B, self.drop_rate, keep.data_ptr())
+        self._site += 1
+        return t.dropout(v, keep, self.drop_rate)
+
     def _encoder(self, t, x, text, sigma, mask, name, B, H, pos_factor):
-        """EncoderLayer.forward (model.py:36-58) with drop_rate 0."""
+        """EncoderLayer.forward (model.py:36-58)."""
         d = x.d.shape[1]
         Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
         tx = self._affine(t, t.layernorm(self._lin(t, t.silu(text), name + ".text_dense")), sigma, name + ".affine0", B)
         text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
-        x2 = t.add(self._affine(t, t.layernorm(x2), sigma, name + ".affine1", B), x)
+        x2 = t.add(self._affine(t, t.layernorm(self._drop(t, x2, B)), sigma, name + ".affine1", B), x)
         x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)
         x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
-        x3 = self._affine(t, t.layernorm(t.add(x2, x3)), sigma, name + ".affine2", B)
-        x4 = t.add(self._ffn(t, x3, name + ".ffn"), x3)
+        x3 = self._affine(t, t.layernorm(t.add(x2, self._drop(t, x3, B))), sigma, name + ".affine2", B)
+        x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn"), B), x3)
         return self._affine(t, t.layernorm(x4), sigma, name + ".affine3", B)
 
     def _text_style(self, t, ids, style, sigma, keep, B):
@@ -441,10 +458,14 @@ class TrainModel:
         if int(text.min()) < 0 or int(text.max()) >= self.p["text_style_model.emb.weight"].d.shape[0]:
             raise ValueError("token id out of the embedding's range")
 
-    def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style: torch.Tensor, style_keep: torch.Tensor | None = None):
+    def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style: torch.Tensor, style_keep: torch.Tensor | None = None,
+                drop_masks=None):
         """strokes [B, L, 2], text int64 [B, Lt] (host), sigma [B, 1] (= sqrt(abar), train.py:49), style [B, S, 1280];
-        ``style_keep``: the Dropout(0.3) keep-mask [B, S, 1280] (drawn here when omitted).  -> (score [B, L, 2], pen [B, L])."""
+        ``style_keep``: the Dropout(0.3) keep-mask [B, S, 1280] (drawn here when omitted); ``drop_masks``: with drop_rate > 0,
+        the EncoderLayers' keep-masks in call order (3 per layer: enc3, enc5, att_layers...), else drawn on the device.
+        -> (score [B, L, 2], pen [B, L])."""
         dev = self.dev
+        self._masks = iter(drop_masks) if drop_masks is not None else None
         f = lambda a: a.to(dev, torch.float32).contiguous()   # noqa: E731
         self.check_tokens(text)
         mask = (text == 0).to(torch.float32).to(dev).contiguous()          # create_padding_mask (utils/nn.py:189), host side
@@ -459,6 +480,7 @@ class TrainModel:
         if L % 8:
             raise ValueError("the stroke length must be a multiple of 8 (three AvgPool1d(2) stages)")
         t = self.tape = Tape(dev)
+        self._site = 3
         x_in, sig_in, sty = Var(strokes.view(B * L, 2)), Var(sigma.view(B, 1)), Var(style)
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
@@ -505,7 +527,7 @@ class _ViewVar(Var):
 
 
 def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch.Tensor, step: int, *, eps: torch.Tensor | None = None,
-               alphas: torch.Tensor | None = None, style_keep: torch.Tensor | None = None, d_model: int = 256,
+               alphas: torch.Tensor | None = None, style_keep: torch.Tensor | None = None, drop_masks=None, d_model: int = 256,
                warmup: int = 10000, lr_mul: float = 1.0):
     """One update, in the reference's order (train.py:26-67): abar draw, eps draw, perturbation, forward, loss, backward,
     (data-parallel gradient mean when torch.distributed is initialised), clip + Adam at the Noam rate of update number ``step`` >= 1.
@@ -519,7 +541,10 @@ def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch
         eps = torch.randn(x.shape)
     x_pert = perturb(x, eps, alphas)
     model.zero_grad()
-    score, pen_pred = model.forward(x_pert, batch["text"], torch.sqrt(alphas), batch["style"], style_keep)
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+    model.rng.copy_(torch.tensor([model.seed, step * world + rank], dtype=torch.int64))
+    score, pen_pred = model.forward(x_pert, batch["text"], torch.sqrt(alphas), batch["style"], style_keep, drop_masks)
     out, d_score, d_pen = loss_fn(eps, score, pen, pen_pred, alphas)
     model.backward(d_score, d_pen)
     grads = model.grads()
@@ -542,7 +567,7 @@ class GraphedTrainStep:
         reference draws them on its device, train.py:39, text_style.py:97); False: the caller passes them (tests)."""
         dev = model.dev
         self.device_rng, self.seed = device_rng, seed
-        self.rng = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.rng = model.rng           # one generator state for the eps / style draws and the model's dropout sites
         self.model, self.opt = model, optimizer
         self.shape = (B, L, Lt, S)
         self.sched = (d_model, warmup, lr_mul)
@@ -588,12 +613,12 @@ class GraphedTrainStep:
         self.model.check_tokens(batch["text"])
         if alphas is None:
             alphas = get_alphas(B, alpha_set)
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        self.rng.copy_(torch.tensor([self.seed, step * world + rank], dtype=torch.int64))
         if self.device_rng:
             if eps is not None or style_keep is not None:
                 raise ValueError("this step draws eps and the dropout mask on the device (device_rng=True)")
-            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-            world = torch.distributed.get_world_size() if rank or (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
-            self.rng.copy_(torch.tensor([self.seed, step * world + rank], dtype=torch.int64))
         else:
             self.eps.copy_(eps if eps is not None else torch.randn(B, L, 2))
             self.keep.copy_(style_keep if style_keep is not None else (torch.rand(B, S, 1280) >= TrainModel.STYLE_DROP).float())

@@ -116,6 +116,9 @@ int dhw_op_embedding(const int64_t* ids, const float* table, long long rows, int
 int dhw_op_embedding_bwd(const int64_t* ids, const float* dy, long long rows, int C, float* dtable, void* hip_stream);
 /* y (+)= x * mask * scale: nn.Dropout with a supplied keep-mask (scale = 1 / (1 - p)), and its backward */
 int dhw_op_mask_mul(const float* x, const float* mask, float scale, long long n, float* y, int accumulate, void* hip_stream);
+/* A Dropout(p) keep-mask drawn on the device for dropout site number `site` >= 3 of the model (EncoderLayer.drop, model.py:23,
+ * 47-56); rng as in dhw_train_draw (sites 1 and 2 are its eps and style mask), per_sample elements per batch sample. */
+int dhw_op_keep_mask(const uint64_t* rng, int site, long long n, int per_sample, float p, float* keep, void* hip_stream);
 /* db[c] += sum over rows of dy[r][c]  (bias gradients) */
 int dhw_op_colsum(const float* dy, long long rows, int C, float* db, void* hip_stream);
 

@@ -129,8 +129,11 @@ def test_embedding_gather_and_scatter():
     _close(vt.g, table.grad)
 
 
-def test_whole_model_gradients_match_the_reference_autograd(golden_dir):
-    f = np.load(os.path.join(golden_dir, "model_grad.npz"))
+@pytest.mark.parametrize("fixture", ["model_grad.npz", "model_grad_drop.npz"])
+def test_whole_model_gradients_match_the_reference_autograd(golden_dir, fixture):
+    """model_grad.npz: drop_rate 0.0 as configs/best.yml trains; model_grad_drop.npz: the class default 0.1 (model.py:71) with the
+    twelve EncoderLayer.drop masks the reference drew replayed in call order."""
+    f = np.load(os.path.join(golden_dir, fixture))
     B, L, Lt, S = (int(f[k]) for k in ("B", "L", "Lt", "S"))
     sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
     names = [str(n) for n in f["names"]]
@@ -139,10 +142,16 @@ def test_whole_model_gradients_match_the_reference_autograd(golden_dir):
     keep = torch.from_numpy(np.unpackbits(f["keep"])[:B * S * 1280].reshape(B, S, 1280).astype(np.float32))
     eps, pen, alphas = (torch.from_numpy(f[k]) for k in ("eps", "pen", "alphas"))
 
-    model = tm.TrainModel({k: sd[k] for k in names}, num_layers=2, device=DEV)
+    drop_rate, masks = 0.0, None
+    if "drop_rate" in f.files:
+        drop_rate = float(f["drop_rate"])
+        bits, sizes = np.unpackbits(f["enc_keep"]), f["enc_keep_sizes"]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        masks = [torch.from_numpy(bits[offs[i]:offs[i + 1]].astype(np.float32)) for i in range(len(sizes))]
+    model = tm.TrainModel({k: sd[k] for k in names}, num_layers=2, device=DEV, drop_rate=drop_rate)
     x_pert = train.perturb(torch.from_numpy(inp["strokes"]), eps, alphas)
     _close(x_pert, torch.from_numpy(f["x_pert"]), 1e-6)
-    score, pen_pred = model.forward(x_pert, torch.from_numpy(inp["text"]), torch.sqrt(alphas), torch.from_numpy(inp["style"]), keep)
+    score, pen_pred = model.forward(x_pert, torch.from_numpy(inp["text"]), torch.sqrt(alphas), torch.from_numpy(inp["style"]), keep, masks)
     _close(score, torch.from_numpy(f["score"]), 5e-5)
     _close(pen_pred, torch.from_numpy(f["pen_pred"]), 5e-5)
     out, d_score, d_pen = train.loss_fn(eps, score, pen, pen_pred, alphas)
@@ -260,3 +269,25 @@ def test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch(tmp_pa
 def spec_flat():
     sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
     return np.concatenate([np.asarray(v, np.float32).ravel() for v in sd.values()])
+
+
+def test_device_drawn_encoder_dropout_trains():
+    """drop_rate 0.1 with the masks drawn by dhw_op_keep_mask inside a graph-replayed step: the masks change from update to
+    update (two replays with the same inputs but different draw indices give different losses), the same index reproduces."""
+    sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    B, L, Lt = 2, 64, 10
+    inp = spec.synthetic_inputs(B, L, Lt, S=14, seed=5, pad=1)
+    g = torch.Generator().manual_seed(5)
+    batch = {"strokes": torch.cat([torch.from_numpy(inp["strokes"]), (torch.rand(B, L, 1, generator=g) < 0.1).float()], dim=-1),
+             "text": torch.from_numpy(inp["text"]), "style": torch.from_numpy(inp["style"])}
+    eps, alphas = torch.randn(B, L, 2, generator=g), torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    keep = (torch.rand(B, 14, 1280, generator=g) >= 0.3).float()
+
+    def first_losses(indices):
+        model = tm.TrainModel(sd, num_layers=2, device=DEV, drop_rate=0.1)
+        opt = train.Adam(model.parameters())
+        step = tm.GraphedTrainStep(model, opt, B, L, Lt, warmup=10 ** 9, device_rng=False)     # lr ~ 0: the weights stay put
+        return [float(step(batch, None, k, eps=eps, alphas=alphas, style_keep=keep)[0]) for k in indices]
+    a = first_losses([1, 2, 1])
+    b = first_losses([1])
+    assert a[0] == b[0] and abs(a[0] - a[1]) > 1e-4 and abs(a[0] - a[2]) < 1e-4, (a, b)
