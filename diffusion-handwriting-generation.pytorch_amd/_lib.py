@@ -104,6 +104,8 @@ SIGNATURES = {
     "dhw_op_embedding_bwd": (C.c_int, [_P, _P, _LL, C.c_int, _P, _P]),
     "dhw_op_mask_mul": (C.c_int, [_P, _P, C.c_float, _LL, _P, C.c_int, _P]),
     "dhw_op_colsum": (C.c_int, [_P, _LL, C.c_int, _P, _P]),
+    "dhw_op_film_table": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "dhw_op_film_table_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "dhw_op_keep_mask": (C.c_int, [_P, C.c_int, _LL, C.c_int, C.c_float, _P, _P]),
     "dhw_debug_randn": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }

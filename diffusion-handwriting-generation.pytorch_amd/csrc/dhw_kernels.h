@@ -230,6 +230,8 @@ struct OpGemm {
   const float* bias; float alpha; int accumulate;
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
+hipError_t launch_film_table(int dir, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int TOT, float* film,
+                             float* gflat, float* dsigma, hipStream_t st);
 hipError_t launch_keep_mask(const uint64_t* rng, int site, long n, int per_sample, float p, float* keep, hipStream_t st);
 hipError_t launch_train_draw(const uint64_t* rng, int B, int L, float* eps, long n_keep, int keep_per_sample, float p, float* keep, hipStream_t st);
 hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* sqnorm, hipStream_t st);

@@ -245,6 +245,19 @@ int dhw_op_keep_mask(const uint64_t* rng, int site, long long n, int per_sample,
   return 0;
 }
 
+int dhw_op_film_table(const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int total, float* film, void* hip_stream) {
+  if (!sigma || !flat || !woff || !boff || !film || B < 1 || total < 1) return tfail(DHW_ERR_ARG, "dhw_op_film_table: bad argument");
+  THIP(launch_film_table(0, sigma, flat, woff, boff, B, total, film, nullptr, nullptr, (hipStream_t)hip_stream));
+  return 0;
+}
+int dhw_op_film_table_bwd(const float* dfilm, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int total,
+                          float* grad_flat, float* dsigma, void* hip_stream) {
+  if (!dfilm || !sigma || !flat || !woff || !boff || !grad_flat || !dsigma || B < 1 || total < 1)
+    return tfail(DHW_ERR_ARG, "dhw_op_film_table_bwd: bad argument");
+  THIP(launch_film_table(1, sigma, flat, woff, boff, B, total, const_cast<float*>(dfilm), grad_flat, dsigma, (hipStream_t)hip_stream));
+  return 0;
+}
+
 #define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
 
 int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {

@@ -627,8 +627,68 @@ __global__ __launch_bounds__(256) void film_bwd2_kernel(const float* d, const fl
   }
 }
 
+// All AffineTransformLayers' gamma / beta Linears (conditioning.py:16-18; 76 Linears of 32 inputs for num_layers = 2) as
+// ONE launch each way.  Column j of the table film[B][TOT] belongs to output channel woff[j] / 32 of some Linear: its weight
+// row starts at flat[woff[j]] (32 floats), its bias is flat[boff[j]] — the parameters stay where the state_dict puts them.
+__global__ __launch_bounds__(256) void film_table_fwd_kernel(const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int TOT,
+                                                              float* film) {
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  __shared__ float sg[32];
+  if (threadIdx.x < 32) sg[threadIdx.x] = sigma[b * 32 + threadIdx.x];
+  __syncthreads();
+  if (j >= TOT) return;
+  const float* w = flat + woff[j];
+  float a = flat[boff[j]];
+#pragma unroll
+  for (int k = 0; k < 32; k += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + k);
+    a += v[0] * sg[k] + v[1] * sg[k + 1] + v[2] * sg[k + 2] + v[3] * sg[k + 3];
+  }
+  film[(long)b * TOT + j] = a;
+}
+// dW[j][k] += sum_b dfilm[b][j] sigma[b][k];  db[j] += sum_b dfilm[b][j]   (one thread per (column, k); B is small)
+__global__ __launch_bounds__(256) void film_table_wgrad_kernel(const float* dfilm, const float* sigma, const int64_t* woff, const int64_t* boff, int B,
+                                                                int TOT, float* gflat) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)TOT * 32) return;
+  const int j = (int)(idx >> 5), k = (int)(idx & 31);
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dfilm[(long)b * TOT + j];
+    s += d * sigma[b * 32 + k];
+    sb += d;
+  }
+  gflat[woff[j] + k] += s;
+  if (k == 0) gflat[boff[j]] += sb;
+}
+// dsigma[b][k] += sum_j dfilm[b][j] W[j][k]: one block per sample, 32 k x 8 column groups, LDS reduction
+__global__ __launch_bounds__(256) void film_table_dgrad_kernel(const float* dfilm, const float* flat, const int64_t* woff, int TOT, float* dsigma) {
+  const int b = blockIdx.x, k = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  float s = 0.f;
+  for (int j = cg; j < TOT; j += 8) s += dfilm[(long)b * TOT + j] * flat[woff[j] + k];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (cg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[k + 32 * i];
+    dsigma[b * 32 + k] += t;
+  }
+}
+
 }  // namespace
 
+hipError_t launch_film_table(int dir, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int TOT, float* film,
+                             float* gflat, float* dsigma, hipStream_t st) {
+  if (dir == 0) {
+    hipLaunchKernelGGL(film_table_fwd_kernel, dim3(nb(TOT), B), dim3(256), 0, st, sigma, flat, woff, boff, TOT, film);
+  } else {
+    hipLaunchKernelGGL(film_table_wgrad_kernel, dim3(nb((long)TOT * 32)), dim3(256), 0, st, film, sigma, woff, boff, B, TOT, gflat);
+    hipLaunchKernelGGL(film_table_dgrad_kernel, dim3(B), dim3(256), 0, st, film, flat, woff, TOT, dsigma);
+  }
+  return hipGetLastError();
+}
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1 || g.taps < 1) return hipErrorInvalidValue;
   if (g.taps > 1 && (g.K % g.taps || (g.K / g.taps) % GK)) return hipErrorInvalidValue;

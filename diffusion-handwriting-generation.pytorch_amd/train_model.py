@@ -239,6 +239,22 @@ class Tape:
         self.record(y, bwd)
         return y
 
+    def film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int) -> Var:
+        """``film`` with gamma / beta taken from columns [col, col + C) of a [B, TOT] table (dhw_op_film_table)."""
+        R, Cc = x.d.shape
+        L, TOT = R // B, table.d.shape[1]
+        y = Var(torch.empty_like(x.d))
+        base = table.d.data_ptr()
+        self.call("dhw_op_film", x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, y.d.data_ptr())
+
+        def bwd():
+            dx, acc = self.into(x)
+            gbase = table.grad().data_ptr()
+            self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), base + col_g * _F, TOT, B, L, Cc, dx.data_ptr(), acc,
+                      gbase + col_g * _F, gbase + col_b * _F)
+        self.record(y, bwd)
+        return y
+
     def layernorm(self, x: Var) -> Var:
         R, Cc = x.d.shape
         y = Var(torch.empty_like(x.d))
@@ -347,13 +363,29 @@ class TrainModel:
         # gradients, a single kernel pair clips and applies Adam, a single all-reduce averages them across ranks.
         self.flat = torch.cat([host[k] for k in self.names]).to(self.dev)
         self.flat_grad = torch.zeros_like(self.flat)
-        self.p, off = {}, 0
+        self.p, self.offset, off = {}, {}, 0
         for k in self.names:
             n = host[k].numel()
             v = Var(self.flat[off:off + n].view(shapes[k]))
             v.g = self.flat_grad[off:off + n].view(shapes[k])
             self.p[k] = v
+            self.offset[k] = off
             off += n
+        # every AffineTransformLayer's gamma / beta Linear as columns of one [B, TOT] table (dhw_op_film_table): column ->
+        # (weight row, bias) offsets inside the flat buffer; film_cols[name] = (first gamma column, first beta column)
+        woff, boff, self.film_cols, col = [], [], {}, 0
+        for k in self.names:
+            if k.endswith(".gamma_emb.weight"):
+                base, Cc = k[:-len(".gamma_emb.weight")], shapes[k][0]
+                if shapes[k][1] != 32:
+                    raise ValueError("the FiLM Linears take the 32-wide sigma embedding")
+                self.film_cols[base] = (col, col + Cc)
+                for kind in ("gamma_emb", "beta_emb"):
+                    woff.append(self.offset[f"{base}.{kind}.weight"] + 32 * torch.arange(Cc, dtype=torch.int64))
+                    boff.append(self.offset[f"{base}.{kind}.bias"] + torch.arange(Cc, dtype=torch.int64))
+                col += 2 * Cc
+        self.film_total = col
+        self.film_woff, self.film_boff = torch.cat(woff).to(self.dev), torch.cat(boff).to(self.dev)
         self.c1 = self.p["input_dense.weight"].d.shape[0]
         self._pe = {}
         self.tape = None
@@ -393,8 +425,18 @@ class TrainModel:
         """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear."""
         return self._lin(t, t.silu(self._lin(t, t.silu(x), name + ".1")), name + ".3")
 
+    def _film_table(self, t, sigma, B):
+        """gamma / beta of all AffineTransformLayers for this sigma: one launch forward, two backward (instead of 76 small
+        GEMMs forward and 228 GEMM / bias-sum launches backward)."""
+        table = Var(t.new(B, self.film_total))
+        args = (self.flat.data_ptr(), self.film_woff.data_ptr(), self.film_boff.data_ptr(), B, self.film_total)
+        t.call("dhw_op_film_table", sigma.d.data_ptr(), *args, table.d.data_ptr())
+        t.record(table, lambda: t.call("dhw_op_film_table_bwd", table.g.data_ptr(), sigma.d.data_ptr(), *args, self.flat_grad.data_ptr(),
+                                       sigma.grad().data_ptr()))
+        self._film = table
+
     def _affine(self, t, x, sigma, name, B):
-        return t.film(x, self._lin(t, sigma, name + ".gamma_emb"), self._lin(t, sigma, name + ".beta_emb"), B)
+        return t.film_cols(x, self._film, *self.film_cols[name], B)
 
     def _mha(self, t, q, k, v, name, B, H, mask=None):
         o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
@@ -484,6 +526,7 @@ class TrainModel:
         x_in, sig_in, sty = Var(strokes.view(B * L, 2)), Var(sigma.view(B, 1)), Var(style)
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
+        self._film_table(t, sigma_v, B)
         txt = self._text_style(t, ids, sty, sigma_v, keep, B)                          # [B*Lt, 2 c2]
         x = self._lin(t, x_in, "input_dense")
         h1 = self._convblock(t, x, sigma_v, "enc1", B, L)

@@ -116,6 +116,14 @@ int dhw_op_embedding(const int64_t* ids, const float* table, long long rows, int
 int dhw_op_embedding_bwd(const int64_t* ids, const float* dy, long long rows, int C, float* dtable, void* hip_stream);
 /* y (+)= x * mask * scale: nn.Dropout with a supplied keep-mask (scale = 1 / (1 - p)), and its backward */
 int dhw_op_mask_mul(const float* x, const float* mask, float scale, long long n, float* y, int accumulate, void* hip_stream);
+/* Every AffineTransformLayer's gamma / beta Linear (conditioning.py:16-18) in one launch: film[b][j] = flat[boff[j]] + sum_k
+ * sigma[b][k] flat[woff[j] + k] for the `total` output channels j of all the Linears; woff / boff (device int64[total]) give
+ * each channel's weight row and bias inside the flat parameter buffer, so the parameters stay in state_dict order.  Backward:
+ * grad_flat[woff[j] + k] += sum_b dfilm[b][j] sigma[b][k], grad_flat[boff[j]] += sum_b dfilm[b][j], dsigma[b][k] += sum_j
+ * dfilm[b][j] flat[woff[j] + k].  sigma / dsigma [B,32], film / dfilm [B,total]. */
+int dhw_op_film_table(const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int total, float* film, void* hip_stream);
+int dhw_op_film_table_bwd(const float* dfilm, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int total,
+                          float* grad_flat, float* dsigma, void* hip_stream);
 /* A Dropout(p) keep-mask drawn on the device for dropout site number `site` >= 3 of the model (EncoderLayer.drop, model.py:23,
  * 47-56); rng as in dhw_train_draw (sites 1 and 2 are its eps and style mask), per_sample elements per batch sample. */
 int dhw_op_keep_mask(const uint64_t* rng, int site, long long n, int per_sample, float p, float* keep, void* hip_stream);
