@@ -391,38 +391,56 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   // staging coordinates of this thread's 8 + 8 elements
   //   A: AM (m along lanes): m = t & 63, k = (t >> 6) + 4 j;   else (k along lanes): k = t & 31, m = (t >> 5) + 8 j
   //   B: BK (k along lanes): k = t & 31, n = (t >> 5) + 8 j;   else (n along lanes): n = t & 63, k = (t >> 6) + 4 j
-  float ra[8], rb[8];
+  // PD K steps of operands are kept in flight in registers; the loads of step s + PD - 1 are issued before step s is staged.
+  // Address arithmetic is kept out of the K loop (it was as long as the MFMA work): each element's offset inside its operand
+  // is a per-thread 32-bit constant, everything that changes from step to step (k position, tap, row shift) is uniform and
+  // goes into the scalar base pointer; the per-step vector work is the validity compares.
+  constexpr int PD = 4;
+  float rar[PD][8], rbr[PD][8];
   const int Kt = g.K / g.taps;                  // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
   const int b_sh = g.b_shift + zi * g.b_z_shift;
-  auto load = [&](int k0) {
+  const unsigned lr_a = g.lr > 0 ? (unsigned)g.lr : 0x7fffffffu;           // no row shift: every row "in range"
+  const unsigned lr_b = b_sh != 0 ? (unsigned)g.lr : 0x7fffffffu;
+  unsigned voa[8], vob[8];
+  int mla[8], klb[8];
+  bool mva[8], nvb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
+    const int m = m0 + am;
+    mva[j] = m < g.M;
+    mla[j] = g.lr > 0 ? m % g.lr : 0;
+    voa[j] = (unsigned)(m * (int)g.sam + ak * (int)g.sak);
+    const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
+    const int n = n0 + bn;
+    nvb[j] = n < g.N;
+    vob[j] = (unsigned)(bk * (int)g.sbk + n * (int)g.sbn);
+    klb[j] = b_sh != 0 ? (k_begin + bk) % g.lr : 0;      // row of the contraction index inside its sample (weight gradients)
+  }
+  int k_next = k_begin;                          // load() is called for consecutive K steps
+  auto load = [&](float (&ra)[8], float (&rb)[8]) {
+    const int k0 = k_next;
+    k_next += GK;
     const int tap = g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
     const int a_sh = g.a_shift + tap * g.a_tap_shift;
-    const float* Bt = B + tap * g.sbt;
+    const int krem = k_end - k0;                 // <= 0 past the end of the slice: nothing is requested
+    const float* Ab = A + (long)a_sh * g.sam + (long)kb * g.sak;
+    const float* Bb = B + tap * g.sbt + (long)(kb + b_sh) * g.sbk;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
-      const int m = m0 + am;
-      bool ok = m < g.M && k0 + ak < k_end;
-      long row = m;
-      if (a_sh != 0) {
-        const int l = m % g.lr + a_sh;
-        ok = ok && l >= 0 && l < g.lr;
-        row = m + a_sh;
+      const int ak = AM ? (t >> 6) + 4 * j : (t & 31);
+      const bool ok = mva[j] && ak < krem && (unsigned)(mla[j] + a_sh) < lr_a;
+      ra[j] = ok ? Ab[voa[j]] : 0.f;
+      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j;
+      const bool okb = nvb[j] && bk < krem && (unsigned)(klb[j] + b_sh) < lr_b;
+      rb[j] = okb ? Bb[vob[j]] : 0.f;
+      if (b_sh != 0) {                           // uniform
+        klb[j] += GK;
+        while (klb[j] >= g.lr) klb[j] -= g.lr;
       }
-      ra[j] = ok ? A[row * g.sam + (long)(kb + ak) * g.sak] : 0.f;
-      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
-      const int kk = kb + bk, n = n0 + bn;
-      bool okb = n < g.N && k0 + bk < k_end;
-      long krow = kk;
-      if (b_sh != 0) {
-        const int l = kk % g.lr + b_sh;
-        okb = okb && l >= 0 && l < g.lr;
-        krow = kk + b_sh;
-      }
-      rb[j] = okb ? Bt[krow * g.sbk + (long)n * g.sbn] : 0.f;
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](const float (&ra)[8], const float (&rb)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
@@ -439,26 +457,33 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
-  if (k_begin < k_end) load(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += GK) {
-    __syncthreads();            // the previous step's fragment reads are done
-    stage();
-    __syncthreads();
-    if (k0 + GK < k_end) load(k0 + GK);
-    Frag<float> fa[2], fb[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const float* pa = As + (wm + 16 * a + i) * GS + 8 * q;
-      fa[a].lo = *reinterpret_cast<const f32x4*>(pa);
-      fa[a].hi = *reinterpret_cast<const f32x4*>(pa + 4);
-      const float* pb = Bs + (wn + 16 * a + i) * GS + 8 * q;
-      fb[a].lo = *reinterpret_cast<const f32x4*>(pb);
-      fb[a].hi = *reinterpret_cast<const f32x4*>(pb + 4);
+  for (int p = 0; p < PD - 1; ++p) load(rar[p], rbr[p]);   // (elements past k_end are not requested)
+  for (int kb = k_begin; kb < k_end; kb += PD * GK) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int k0 = kb + p * GK;
+      if (k0 < k_end) {         // uniform over the workgroup
+        load(rar[(p + PD - 1) % PD], rbr[(p + PD - 1) % PD]);
+        __syncthreads();        // the previous step's fragment reads are done
+        stage(rar[p], rbr[p]);
+        __syncthreads();
+        Frag<float> fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float* pa = As + (wm + 16 * a + i) * GS + 8 * q;
+          fa[a].lo = *reinterpret_cast<const f32x4*>(pa);
+          fa[a].hi = *reinterpret_cast<const f32x4*>(pa + 4);
+          const float* pb = Bs + (wn + 16 * a + i) * GS + 8 * q;
+          fb[a].lo = *reinterpret_cast<const f32x4*>(pb);
+          fb[a].hi = *reinterpret_cast<const f32x4*>(pb + 4);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
+      }
     }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
   }
 
   // acc[a][b][r] = C[m0 + wm + 16 a + 4 q + r][n0 + wn + 16 b + i]
@@ -661,11 +686,13 @@ __global__ __launch_bounds__(256) void film_table_wgrad_kernel(const float* dfil
   gflat[woff[j] + k] += s;
   if (k == 0) gflat[boff[j]] += sb;
 }
-// dsigma[b][k] += sum_j dfilm[b][j] W[j][k]: one block per sample, 32 k x 8 column groups, LDS reduction
+// dsigma[b][k] += sum_j dfilm[b][j] W[j][k]: block = (sample, chunk of 1024 columns), 32 k x 8 column groups, LDS reduction,
+// one atomic per (block, k)
 __global__ __launch_bounds__(256) void film_table_dgrad_kernel(const float* dfilm, const float* flat, const int64_t* woff, int TOT, float* dsigma) {
-  const int b = blockIdx.x, k = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int b = blockIdx.y, k = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int j0 = blockIdx.x * 1024, j1 = min(TOT, j0 + 1024);
   float s = 0.f;
-  for (int j = cg; j < TOT; j += 8) s += dfilm[(long)b * TOT + j] * flat[woff[j] + k];
+  for (int j = j0 + cg; j < j1; j += 8) s += dfilm[(long)b * TOT + j] * flat[woff[j] + k];
   __shared__ float red[256];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -673,7 +700,7 @@ __global__ __launch_bounds__(256) void film_table_dgrad_kernel(const float* dfil
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[k + 32 * i];
-    dsigma[b * 32 + k] += t;
+    atomicAdd(dsigma + b * 32 + k, t);
   }
 }
 
@@ -685,7 +712,7 @@ hipError_t launch_film_table(int dir, const float* sigma, const float* flat, con
     hipLaunchKernelGGL(film_table_fwd_kernel, dim3(nb(TOT), B), dim3(256), 0, st, sigma, flat, woff, boff, TOT, film);
   } else {
     hipLaunchKernelGGL(film_table_wgrad_kernel, dim3(nb((long)TOT * 32)), dim3(256), 0, st, film, sigma, woff, boff, B, TOT, gflat);
-    hipLaunchKernelGGL(film_table_dgrad_kernel, dim3(B), dim3(256), 0, st, film, flat, woff, TOT, dsigma);
+    hipLaunchKernelGGL(film_table_dgrad_kernel, dim3(nb(TOT, 1024), B), dim3(256), 0, st, film, flat, woff, TOT, dsigma);
   }
   return hipGetLastError();
 }

@@ -26,12 +26,14 @@ _F = 4  # bytes per element
 
 
 class Var:
-    """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient."""
-    __slots__ = ("d", "g")
+    """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient.  ``leaf``: a network input
+    whose gradient nobody needs (the backward sweep skips the kernels that would only produce it)."""
+    __slots__ = ("d", "g", "leaf")
 
-    def __init__(self, d: torch.Tensor):
+    def __init__(self, d: torch.Tensor, leaf: bool = False):
         self.d = d
         self.g = None
+        self.leaf = leaf
 
     def grad(self) -> torch.Tensor:
         if self.g is None:
@@ -108,6 +110,8 @@ class Tape:
         if extent(a_off, sam, M, sak, Kt, za) >= A.numel() or extent(b_off, sbk, Kt, sbn, N, zb, sbt) >= Bm.numel() \
                 or extent(c_off, scm, M, scn, N, zc) >= Cm.numel() or min(a_off, b_off, c_off) < 0:
             raise ValueError("gemm operand extents exceed their buffers")
+        if max(A.numel(), Bm.numel()) >= 2 ** 31:
+            raise ValueError("gemm operands are addressed with 32-bit element offsets")
         if (a_shift or a_tap_shift) and (lr < 1 or M % lr):
             raise ValueError("a row-shifted gemm needs whole samples of lr rows")
         if (b_shift or b_z_shift) and (lr < 1 or Kt % lr):
@@ -140,13 +144,17 @@ class Tape:
         """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]."""
         R, K = x.d.shape
         N = W.d.shape[0]
-        y = Var(self.new(R, N))
-        self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None)
+        # few output tiles and a long contraction (sigma_ffn's 2048 -> 32): zero the output and let the GEMM split K over
+        # workgroups with atomics, instead of one workgroup walking all of K
+        split = -(-R // 64) * -(-N // 64) < 64 and K >= 512
+        y = Var(torch.zeros(R, N, device=self.dev) if split else self.new(R, N))
+        self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None, acc=split)
 
         def bwd():
             dy = y.g
-            dx, acc = self.into(x)
-            self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)                 # dx (+)= dy W
+            if not x.leaf:
+                dx, acc = self.into(x)
+                self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)             # dx (+)= dy W
             dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
             self.fork(dy, x.d)
             self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True)         # dW += dy^T x
@@ -188,11 +196,13 @@ class Tape:
         return y
 
     def unary(self, kind: int, x: Var) -> Var:
-        y = Var(torch.empty_like(x.d))
+        y = Var(torch.empty_like(x.d), leaf=x.leaf)     # a function of inputs only needs no gradient either
         n = x.d.numel()
         self.call("dhw_op_unary", kind, x.d.data_ptr(), n, y.d.data_ptr())
         saved = x.d if kind == 0 else y.d
         def bwd():
+            if x.leaf:
+                return
             dx, acc = self.into(x)
             self.call("dhw_op_unary_bwd", kind, y.g.data_ptr(), saved.data_ptr(), n, dx.data_ptr(), acc)
         self.record(y, bwd)
@@ -317,11 +327,13 @@ class Tape:
 
     def dropout(self, x: Var, keep: torch.Tensor, p: float) -> Var:
         """nn.Dropout(p) with the keep-mask supplied (1 = kept)."""
-        y = Var(torch.empty_like(x.d))
+        y = Var(torch.empty_like(x.d), leaf=x.leaf)
         n = x.d.numel()
         scale = 1.0 / (1.0 - p)
         self.call("dhw_op_mask_mul", x.d.data_ptr(), keep.data_ptr(), scale, n, y.d.data_ptr(), 0)
         def bwd():
+            if x.leaf:
+                return
             dx, acc = self.into(x)
             self.call("dhw_op_mask_mul", y.g.data_ptr(), keep.data_ptr(), scale, n, dx.data_ptr(), acc)
         self.record(y, bwd)
@@ -523,7 +535,7 @@ class TrainModel:
             raise ValueError("the stroke length must be a multiple of 8 (three AvgPool1d(2) stages)")
         t = self.tape = Tape(dev)
         self._site = 3
-        x_in, sig_in, sty = Var(strokes.view(B * L, 2)), Var(sigma.view(B, 1)), Var(style)
+        x_in, sig_in, sty = Var(strokes.view(B * L, 2), leaf=True), Var(sigma.view(B, 1), leaf=True), Var(style, leaf=True)
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
         self._film_table(t, sigma_v, B)
@@ -562,6 +574,7 @@ class _ViewVar(Var):
         self.base, self.shape = base, shape
         self.d = base.d.view(*shape)
         self.g = None
+        self.leaf = base.leaf
 
     def grad(self):
         if self.g is None:
