@@ -374,7 +374,7 @@ namespace {
 // — weight gradients contract over all B*L stroke rows into a few small tiles, and would otherwise run on a few CUs.
 constexpr int GT = 64, GK = 32, GS = 36;
 
-template <bool AM, bool BK>
+template <bool AM, bool BK, bool AV, bool BV>
 __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int tiles_n, int ksplit, int kslice) {
   __shared__ __attribute__((aligned(16))) float As[GT * GS];
   __shared__ __attribute__((aligned(16))) float Bs[GT * GS];
@@ -388,34 +388,44 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   float* C = g.C + zo * g.sczo + zi * g.sczi;
   const int k_begin = ks * kslice, k_end = min(g.K, k_begin + kslice);
 
-  // staging coordinates of this thread's 8 + 8 elements
+  // Staging coordinates of this thread's 8 + 8 elements per K step.  Scalar form (one dword per load):
   //   A: AM (m along lanes): m = t & 63, k = (t >> 6) + 4 j;   else (k along lanes): k = t & 31, m = (t >> 5) + 8 j
   //   B: BK (k along lanes): k = t & 31, n = (t >> 5) + 8 j;   else (n along lanes): n = t & 63, k = (t >> 6) + 4 j
+  // Vector form (AV / BV: the lane index has stride exactly 1 and everything is 16-byte aligned), two 16-byte loads:
+  //   A: AM: m = 4 (t & 15) .. +3 at k = (t >> 4) + 16 jj;     else: k = 4 (t & 7) .. +3 of row m = (t >> 3) + 32 jj
+  //   B: BK: k = 4 (t & 7) .. +3 of column n = (t >> 3) + 32 jj;   else: n = 4 (t & 15) .. +3 at k = (t >> 4) + 16 jj
   // PD K steps of operands are kept in flight in registers; the loads of step s + PD - 1 are issued before step s is staged.
   // Address arithmetic is kept out of the K loop (it was as long as the MFMA work): each element's offset inside its operand
   // is a per-thread 32-bit constant, everything that changes from step to step (k position, tap, row shift) is uniform and
   // goes into the scalar base pointer; the per-step vector work is the validity compares.
   constexpr int PD = 4;
+  constexpr int NA = AV ? 2 : 8, NB = BV ? 2 : 8;      // loads per thread and step
   float rar[PD][8], rbr[PD][8];
   const int Kt = g.K / g.taps;                  // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
   const int b_sh = g.b_shift + zi * g.b_z_shift;
   const unsigned lr_a = g.lr > 0 ? (unsigned)g.lr : 0x7fffffffu;           // no row shift: every row "in range"
   const unsigned lr_b = b_sh != 0 ? (unsigned)g.lr : 0x7fffffffu;
-  unsigned voa[8], vob[8];
-  int mla[8], klb[8];
-  bool mva[8], nvb[8];
+  // local (tile) coordinates of load j: (am, ak) / (bn, bk); for a vector load the first of its 4 elements
+  auto a_m = [&](int j) { return AV ? (AM ? 4 * (t & 15) : (t >> 3) + 32 * j) : (AM ? (t & 63) : (t >> 5) + 8 * j); };
+  auto a_k = [&](int j) { return AV ? (AM ? (t >> 4) + 16 * j : 4 * (t & 7)) : (AM ? (t >> 6) + 4 * j : (t & 31)); };
+  auto b_n = [&](int j) { return BV ? (BK ? (t >> 3) + 32 * j : 4 * (t & 15)) : (BK ? (t >> 5) + 8 * j : (t & 63)); };
+  auto b_k = [&](int j) { return BV ? (BK ? 4 * (t & 7) : (t >> 4) + 16 * j) : (BK ? (t & 31) : (t >> 6) + 4 * j); };
+  unsigned voa[NA], vob[NB];
+  int mla[NA], klb[NB];
+  bool mva[NA], nvb[NB];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
-    const int m = m0 + am;
-    mva[j] = m < g.M;
+  for (int j = 0; j < NA; ++j) {
+    const int m = m0 + a_m(j);
+    mva[j] = m < g.M;                            // (a vector load's 4 rows / 4 k are valid together: M, K multiples of 4)
     mla[j] = g.lr > 0 ? m % g.lr : 0;
-    voa[j] = (unsigned)(m * (int)g.sam + ak * (int)g.sak);
-    const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
-    const int n = n0 + bn;
+    voa[j] = (unsigned)(m * (int)g.sam + a_k(j) * (int)g.sak);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + b_n(j);
     nvb[j] = n < g.N;
-    vob[j] = (unsigned)(bk * (int)g.sbk + n * (int)g.sbn);
-    klb[j] = b_sh != 0 ? (k_begin + bk) % g.lr : 0;      // row of the contraction index inside its sample (weight gradients)
+    vob[j] = (unsigned)(b_k(j) * (int)g.sbk + n * (int)g.sbn);
+    klb[j] = b_sh != 0 ? (k_begin + b_k(j)) % g.lr : 0;   // row of the contraction index inside its sample (weight gradients)
   }
   int k_next = k_begin;                          // load() is called for consecutive K steps
   auto load = [&](float (&ra)[8], float (&rb)[8]) {
@@ -427,13 +437,24 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
     const float* Ab = A + (long)a_sh * g.sam + (long)kb * g.sak;
     const float* Bb = B + tap * g.sbt + (long)(kb + b_sh) * g.sbk;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ak = AM ? (t >> 6) + 4 * j : (t & 31);
-      const bool ok = mva[j] && ak < krem && (unsigned)(mla[j] + a_sh) < lr_a;
-      ra[j] = ok ? Ab[voa[j]] : 0.f;
-      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j;
-      const bool okb = nvb[j] && bk < krem && (unsigned)(klb[j] + b_sh) < lr_b;
-      rb[j] = okb ? Bb[vob[j]] : 0.f;
+    for (int j = 0; j < NA; ++j) {
+      const bool ok = mva[j] && a_k(j) < krem && (unsigned)(mla[j] + a_sh) < lr_a;
+      if constexpr (AV) {
+        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(Ab + voa[j]) : (f32x4){0, 0, 0, 0};
+        ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
+      } else {
+        ra[j] = ok ? Ab[voa[j]] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool okb = nvb[j] && b_k(j) < krem && (unsigned)(klb[j] + b_sh) < lr_b;
+      if constexpr (BV) {
+        const f32x4 v = okb ? *reinterpret_cast<const f32x4*>(Bb + vob[j]) : (f32x4){0, 0, 0, 0};
+        rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+      } else {
+        rb[j] = okb ? Bb[vob[j]] : 0.f;
+      }
       if (b_sh != 0) {                           // uniform
         klb[j] += GK;
         while (klb[j] >= g.lr) klb[j] -= g.lr;
@@ -442,11 +463,20 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   };
   auto stage = [&](const float (&ra)[8], const float (&rb)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int am = AM ? (t & 63) : (t >> 5) + 8 * j, ak = AM ? (t >> 6) + 4 * j : (t & 31);
-      As[am * GS + ak] = ra[j];
-      const int bk = BK ? (t & 31) : (t >> 6) + 4 * j, bn = BK ? (t >> 5) + 8 * j : (t & 63);
-      Bs[bn * GS + bk] = rb[j];
+    for (int j = 0; j < NA; ++j) {
+      if constexpr (AV && !AM) *reinterpret_cast<f32x4*>(As + a_m(j) * GS + a_k(j)) = (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+      else if constexpr (AV) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(a_m(j) + e) * GS + a_k(j)] = ra[4 * j + e];
+      } else As[a_m(j) * GS + a_k(j)] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if constexpr (BV && BK) *reinterpret_cast<f32x4*>(Bs + b_n(j) * GS + b_k(j)) = (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+      else if constexpr (BV) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(b_n(j) + e) * GS + b_k(j)] = rb[4 * j + e];
+      } else Bs[b_n(j) * GS + b_k(j)] = rb[j];
     }
   };
 
@@ -728,12 +758,23 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;
   const dim3 grid((unsigned)(tiles_m * tiles_n * ksplit), g.nzo * g.nzi), block(256);
-  // lanes run along the index whose stride is the smaller one
+  // lanes run along the index whose stride is the smaller one; 16-byte loads where that stride is 1 and everything is aligned
   const bool am = std::llabs(g.sam) < std::llabs(g.sak), bk = std::llabs(g.sbk) < std::llabs(g.sbn);
-  if (am && bk) hipLaunchKernelGGL((sgemm_tiled_kernel<true, true>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
-  else if (am) hipLaunchKernelGGL((sgemm_tiled_kernel<true, false>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
-  else if (bk) hipLaunchKernelGGL((sgemm_tiled_kernel<false, true>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
-  else hipLaunchKernelGGL((sgemm_tiled_kernel<false, false>), grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool av = am ? (g.sam == 1 && g.sak % 4 == 0 && g.M % 4 == 0 && g.a_shift == 0 && g.a_tap_shift == 0)
+               : (g.sak == 1 && g.sam % 4 == 0 && g.K % 4 == 0);
+  av = av && al16(g.A) && g.sazo % 4 == 0 && g.sazi % 4 == 0;
+  bool bv = bk ? (g.sbk == 1 && g.sbn % 4 == 0 && g.K % 4 == 0 && g.b_shift == 0 && g.b_z_shift == 0)
+               : (g.sbn == 1 && g.sbk % 4 == 0 && g.N % 4 == 0);
+  bv = bv && al16(g.B) && g.sbzo % 4 == 0 && g.sbzi % 4 == 0 && g.sbt % 4 == 0;
+  static const bool novec = [] { const char* e = getenv("DHW_SGEMM_SCALAR"); return e && *e == '1'; }();
+  if (novec) av = bv = false;
+  using KFn = void (*)(const OpGemm, int, int, int);
+#define DHW_SG4(AM_, BK_) sgemm_tiled_kernel<AM_, BK_, false, false>, sgemm_tiled_kernel<AM_, BK_, false, true>, \
+                          sgemm_tiled_kernel<AM_, BK_, true, false>, sgemm_tiled_kernel<AM_, BK_, true, true>
+  static const KFn variants[16] = {DHW_SG4(false, false), DHW_SG4(false, true), DHW_SG4(true, false), DHW_SG4(true, true)};
+#undef DHW_SG4
+  hipLaunchKernelGGL(variants[am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, tiles_n, ksplit, kslice);
   return hipGetLastError();
 }
 hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {
