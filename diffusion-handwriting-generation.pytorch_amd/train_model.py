@@ -702,3 +702,87 @@ class GraphedTrainStep:
     def grad_norm(self) -> float:
         """||g|| of the last update before clipping (one host synchronisation)."""
         return float(self.sqnorm.sqrt())
+
+
+def read_train_config(config_path) -> dict:
+    """The keys of a reference experiment config the training loop uses (configs/best.yml; train.py:136-151).  Missing keys
+    raise, as attribute access on the reference's config object does."""
+    import yaml
+    with open(config_path) as f:
+        cfg = yaml.safe_load(f) or {}
+    ta, ds, opt = cfg.get("training_args"), cfg.get("dataset_args"), (cfg.get("optimizer") or {}).get("params")
+    for name, sec in (("training_args", ta), ("dataset_args", ds), ("optimizer.params", opt)):
+        if not isinstance(sec, dict):
+            raise KeyError(f"{config_path}: no `{name}` section")
+    need = ("steps", "batch_size", "warmup_steps", "clip_grad", "dropout", "att_layers_num", "channels", "log_freq", "save_freq")
+    missing = [k for k in need if k not in ta] + [f"dataset_args.{k}" for k in ("max_seq_len", "max_text_len") if k not in ds]
+    if missing:
+        raise KeyError(f"{config_path}: missing {', '.join(missing)}")
+    ch = int(ta["channels"])
+    return {"steps": int(ta["steps"]), "batch_size": int(ta["batch_size"]), "warmup": int(ta["warmup_steps"]),
+            "clip_grad": None if ta["clip_grad"] is None else float(ta["clip_grad"]), "dropout": float(ta["dropout"]),
+            "num_layers": int(ta["att_layers_num"]), "c1": ch, "c2": ch * 3 // 2, "c3": ch * 2, "log_freq": int(ta["log_freq"]),
+            "save_freq": int(ta["save_freq"]), "L": int(ds["max_seq_len"]), "Lt": int(ds["max_text_len"]),
+            "betas": tuple(float(b) for b in opt.get("betas", (0.9, 0.999))), "weight_decay": float(opt.get("weight_decay", 0.0)),
+            "seed": int((cfg.get("experiment") or {}).get("seed", 0))}
+
+
+def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, seed=0, log=print):
+    """The reference's ``TrainingLoop.train`` (train.py:84-134): updates until ``training_args.steps``, a log line every
+    ``log_freq`` updates (mean losses since the last line), ``checkpoint_<n>.pth`` every ``save_freq``, ``model_final.pth`` at
+    the end.  One process per GPU under ``torch.distributed.run`` (LOCAL_RANK picks the device, gradients averaged by RCCL);
+    rank 0 logs and saves.  Returns the trained ``TrainModel``."""
+    import os
+    import time
+    from . import spec
+    from .checkpoint import read_state_dict
+    cfg = read_train_config(config_path)
+    n_steps = steps if steps is not None else cfg["steps"]
+    dist = torch.distributed
+    world, rank = 1, 0
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, L, Lt = cfg["batch_size"], cfg["L"], cfg["Lt"]
+    if L % 8:
+        raise ValueError("dataset_args.max_seq_len must be a multiple of 8 (configs/best.yml:12)")
+    sd = read_state_dict(init) if init else spec.synthetic_state_dict(cfg["num_layers"], cfg["c1"], cfg["c2"], cfg["c3"], seed=seed)
+    model = TrainModel(sd, num_layers=cfg["num_layers"], device=dev, drop_rate=cfg["dropout"], seed=seed)
+    opt = Adam(model.parameters(), betas=cfg["betas"], weight_decay=cfg["weight_decay"], max_norm=cfg["clip_grad"] or 0.0)
+    step_fn = GraphedTrainStep(model, opt, B, L, Lt, d_model=2 * cfg["c1"], warmup=cfg["warmup"], seed=seed)
+    alpha_set = torch.cumprod(1 - (0.02 + torch.exp(torch.linspace(math.log(1e-5), math.log(0.4), 60))), dim=0)   # utils/nn.py:19-39
+    gen = torch.Generator().manual_seed(cfg["seed"] * 1000 + rank)
+    data = None
+    if data_path:
+        data = torch.load(data_path, map_location="cpu", weights_only=True)
+        for k, shape in (("strokes", (L, 3)), ("text", (Lt,)), ("style", (14, 1280))):
+            if k not in data or tuple(data[k].shape[1:]) != shape:
+                raise ValueError(f"{data_path}: `{k}` must be [N, {', '.join(map(str, shape))}]")
+
+    def next_batch():
+        if data is not None:                      # a random batch, as `next(iter(shuffled loader))` gives (train.py:99)
+            idx = torch.randint(0, data["strokes"].shape[0], (B,), generator=gen)
+            return {k: data[k][idx] for k in ("strokes", "text", "style")}
+        pen = (torch.rand(B, L, 1, generator=gen) < 0.1).float()
+        return {"strokes": torch.cat([torch.randn(B, L, 2, generator=gen), pen], dim=-1),
+                "text": torch.randint(1, 73, (B, Lt), generator=gen), "style": torch.randn(B, 14, 1280, generator=gen).abs()}
+
+    os.makedirs(out_dir, exist_ok=True)
+    acc, t0 = [], time.time()
+    for count in range(1, n_steps + 1):
+        acc.append(step_fn(next_batch(), alpha_set, count).clone())
+        if count % cfg["log_freq"] == 0:
+            m = torch.stack(acc).mean(0).tolist()   # (one host sync per log line)
+            acc = []
+            if rank == 0:
+                log(f"Step {count} | Loss: {m[0]:.3f} | Score: {m[1]:.3f} | Pen: {m[2]:.3f} | Time: {time.time() - t0:.3f} sec")
+        if rank == 0 and count % cfg["save_freq"] == 0:
+            torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"checkpoint_{count}.pth"))
+    if rank == 0:
+        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "model_final.pth"))
+    if world > 1:
+        dist.barrier()
+    return model

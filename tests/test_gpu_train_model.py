@@ -291,3 +291,29 @@ def test_device_drawn_encoder_dropout_trains():
     a = first_losses([1, 2, 1])
     b = first_losses([1])
     assert a[0] == b[0] and abs(a[0] - a[1]) > 1e-4 and abs(a[0] - a[2]) < 1e-4, (a, b)
+
+
+def test_fit_trains_and_its_checkpoint_feeds_the_sampler(tmp_path):
+    """train.py / fit(): the reference's loop shape (train.py:84-134) on synthetic batches — log lines in its format,
+    checkpoint_<n>.pth and model_final.pth as torch-saved state_dicts with the reference's keys, which the sampling side
+    (load_model -> sample) takes as they are."""
+    cfg = tmp_path / "cfg.yml"
+    cfg.write_text("""
+experiment: {seed: 1}
+dataset_args: {max_seq_len: 64, max_text_len: 8}
+training_args: {steps: 4, batch_size: 2, warmup_steps: 100, clip_grad: 100.0, dropout: 0.1, att_layers_num: 2, channels: 128, log_freq: 2, save_freq: 3}
+optimizer: {type: torch.optim.Adam, params: {lr: 0.0003, weight_decay: 0.00001, betas: [0.9, 0.98]}}
+""")
+    lines = []
+    tm.fit(cfg, None, tmp_path / "run", log=lines.append)
+    assert len(lines) == 2 and lines[0].startswith("Step 2 | Loss: ") and " | Score: " in lines[1] and " | Pen: " in lines[1]
+    assert (tmp_path / "run" / "checkpoint_3.pth").exists()
+    sd = torch.load(tmp_path / "run" / "model_final.pth", weights_only=True)
+    ref_keys = list(spec.synthetic_state_dict(2))
+    assert list(sd) == ref_keys and all(torch.isfinite(v).all() for v in sd.values())
+    moved = max(float((sd[k] - torch.from_numpy(spec.synthetic_state_dict(2, seed=0)[k])).abs().max()) for k in ref_keys)
+    assert moved > 0
+    model = dhg_amd.load_model(cfg, tmp_path / "run" / "model_final.pth")
+    inp = spec.synthetic_inputs(2, 64, 8, seed=2)
+    out = dhg_amd.sample(model, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=64, T=2, seed=3)
+    assert out.shape == (2, 64, 3) and bool(torch.isfinite(out).all())

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -55,3 +56,38 @@ def test_gradient_allreduce_averages_over_ranks_gloo():
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+BEST_YML = """
+experiment: {name: x, seed: 54321}
+dataset_args: {max_seq_len: 480, max_text_len: 50, img_height: 96, img_width: 1400}
+training_args:
+  steps: 60000
+  batch_size: 96
+  warmup_steps: 10000
+  clip_grad: 100.0
+  dropout: 0.0
+  att_layers_num: 2
+  channels: 128
+  log_freq: 5
+  save_freq: 1000
+optimizer:
+  type: torch.optim.Adam
+  params: {lr: 0.0003, weight_decay: 0.00001, betas: [0.9, 0.98]}
+"""
+
+
+def test_train_config_keys_of_the_reference_yml(tmp_path):
+    """configs/best.yml's training keys (train.py:136-151) -> what fit() uses; an incomplete config raises like the reference's
+    attribute access does."""
+    from dhg_amd import train_model
+    p = tmp_path / "best.yml"
+    p.write_text(BEST_YML)
+    c = train_model.read_train_config(p)
+    assert (c["steps"], c["batch_size"], c["warmup"], c["clip_grad"], c["dropout"]) == (60000, 96, 10000, 100.0, 0.0)
+    assert (c["num_layers"], c["c1"], c["c2"], c["c3"], c["L"], c["Lt"]) == (2, 128, 192, 256, 480, 50)
+    assert c["betas"] == (0.9, 0.98) and c["weight_decay"] == 1e-5 and c["seed"] == 54321
+    bad = tmp_path / "bad.yml"
+    bad.write_text(BEST_YML.replace("  warmup_steps: 10000\n", ""))
+    with pytest.raises(KeyError, match="warmup_steps"):
+        train_model.read_train_config(bad)
