@@ -317,3 +317,22 @@ optimizer: {type: torch.optim.Adam, params: {lr: 0.0003, weight_decay: 0.00001, 
     inp = spec.synthetic_inputs(2, 64, 8, seed=2)
     out = dhg_amd.sample(model, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=64, T=2, seed=3)
     assert out.shape == (2, 64, 3) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("num_layers,B,L,Lt,S", [(2, 3, 72, 7, 14), (4, 2, 40, 12, 14), (2, 1, 8, 1, 1)])
+def test_training_forward_equals_the_inference_forward_when_nothing_is_dropped(num_layers, B, L, Lt, S):
+    """The two native forwards of the same model — the training one (generic fp32 ops, torch layouts) and the sampler's fused
+    fp32 kernels (packed weights; pinned to the reference by the goldens) — on shapes the gradient fixtures do not cover:
+    num_layers = 4 (the class default, model.py:66), odd token counts, the smallest legal L, a one-row style.  A keep-mask of
+    0.7 everywhere makes Dropout(0.3) the identity (0.7 / (1 - 0.3) = 1)."""
+    sd = spec.synthetic_state_dict(num_layers, 128, 192, 256, seed=4)
+    inp = spec.synthetic_inputs(B, L, Lt, S=S, seed=8, pad=min(2, Lt - 1))
+    sigma = torch.linspace(0.2, 0.9, B).reshape(B, 1)
+    strokes, text, style = (torch.from_numpy(inp[k]) for k in ("strokes", "text", "style"))
+    infer = dhg_amd.DiffusionModel(num_layers, precision="fp32").eval()
+    infer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    eps_ref, pen_ref, _ = infer(strokes.cuda(), text.cuda(), sigma.cuda(), style.cuda())
+    model = tm.TrainModel(sd, num_layers=num_layers, device=DEV)
+    score, pen = model.forward(strokes, text, sigma, style, torch.full((B, S, 1280), 0.7))
+    _close(score, eps_ref, 2e-5)
+    _close(pen, pen_ref, 2e-5)
