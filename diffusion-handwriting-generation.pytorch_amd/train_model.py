@@ -780,7 +780,9 @@ def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, 
             if rank == 0:
                 log(f"Step {count} | Loss: {m[0]:.3f} | Score: {m[1]:.3f} | Pen: {m[2]:.3f} | Time: {time.time() - t0:.3f} sec")
         if rank == 0 and count % cfg["save_freq"] == 0:
-            torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"checkpoint_{count}.pth"))
+            # save_checkpoint's form (checkpoint.py:244): {"meta", "state_dict"}; model_final.pth is the bare state_dict (train.py:131)
+            torch.save({"meta": None, "state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
+                       os.path.join(out_dir, f"checkpoint_{count}.pth"))
     if rank == 0:
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "model_final.pth"))
     if world > 1:

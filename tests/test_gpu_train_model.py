@@ -308,7 +308,9 @@ optimizer: {type: torch.optim.Adam, params: {lr: 0.0003, weight_decay: 0.00001, 
     lines = []
     tm.fit(cfg, None, tmp_path / "run", log=lines.append)
     assert len(lines) == 2 and lines[0].startswith("Step 2 | Loss: ") and " | Score: " in lines[1] and " | Pen: " in lines[1]
-    assert (tmp_path / "run" / "checkpoint_3.pth").exists()
+    ck = torch.load(tmp_path / "run" / "checkpoint_3.pth", weights_only=True)
+    assert set(ck) == {"meta", "state_dict"} and len(ck["state_dict"]) == 323            # save_checkpoint's form (checkpoint.py:244)
+    assert dhg_amd.find_checkpoint(tmp_path / "run").name == "model_final.pth"
     sd = torch.load(tmp_path / "run" / "model_final.pth", weights_only=True)
     ref_keys = list(spec.synthetic_state_dict(2))
     assert list(sd) == ref_keys and all(torch.isfinite(v).all() for v in sd.values())
