@@ -25,6 +25,16 @@ def main(argv=None):
     ap.add_argument("--init", help="state_dict to start from (.pth)")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
+    # the host side draws abar and assembles batches with small torch CPU ops: one thread per visible core on a box whose
+    # cgroup grants fewer makes each of them take milliseconds
+    import os
+    import torch
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        cores = os.cpu_count() if quota == "max" else max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, 16)))
     dhg_amd.train_model.fit(a.config, a.data, a.out, steps=a.steps, init=a.init, seed=a.seed)
 
 
