@@ -52,10 +52,11 @@ def parse_args(argv=None):
     ap.add_argument("--Lt", type=int, default=None, help="text length (default 30; 50 with --train)")
     ap.add_argument("--T", type=int, default=60)
     ap.add_argument("--num-layers", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                    help="default bf16 (sampling: the reference's compute dtype target) / fp32 with --train (the reference trains in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-mode throughput figure")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the other-precision throughput figure (fp32_mode; bf16_mode with --train)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="concurrent prompt sub-batches per GPU (0 = library default)")
     # launcher / distributed plumbing rehearsal on CPU (tests/test_bench_launcher_cpu.py): gloo, no GPU, no library
@@ -65,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
+    a.precision = a.precision or ("fp32" if a.train else "bf16")
     a.batch = a.batch or (32 if a.train else 64)
     a.L = a.L or (480 if a.train else 488)
     a.Lt = a.Lt or (50 if a.train else 30)
@@ -268,7 +270,7 @@ def train_worker(args, dev, dist, rank, world):
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     B, L, Lt = args.batch, args.L, args.Lt
     sd = spec.synthetic_state_dict(args.num_layers, 128, 192, 256, seed=0)
-    model = tm.TrainModel(sd, num_layers=args.num_layers, device=dev)
+    model = tm.TrainModel(sd, num_layers=args.num_layers, device=dev, precision=args.precision)
     opt = train.Adam(model.parameters())
     inp = spec.synthetic_inputs_range(rank * B, B, L, Lt, seed=3, T=0)
     g = torch.Generator().manual_seed(3 + rank)
@@ -314,7 +316,8 @@ def train_worker(args, dev, dist, rank, world):
     gemm_tflops = model.last_gemm_flops * args.steps / dt_own / 1e12
     res = {"metric": "training samples/sec (forward + loss + backward + grad all-reduce + clip + Adam; L=480)", "value": value,
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 GEMM operands, f32 accumulate / state",
+           "data": "synthetic",
            "config": {"workload": f"configs[4]: training step, batch={B}/GPU, L={L}, Lt={Lt}, d_model=128/192/256, num_layers={args.num_layers}, "
                                   "dropout 0.0 + style Dropout(0.3), Adam + Noam + clip 100, random-init weights",
                       "global_batch": world * B, "seq_len": L,
@@ -327,6 +330,19 @@ def train_worker(args, dev, dist, rank, world):
     if args.share_gpu:
         res["data"] = "synthetic; REHEARSAL: ranks share GPUs (not a scaling measurement)"
     if rank == 0:
+        if world == 1 and args.precision == "fp32" and not args.no_fp32:
+            # the same update with mixed-precision GEMMs (bf16-rounded operands, fp32 accumulation, fp32 master weights)
+            m2 = tm.TrainModel(sd, num_layers=args.num_layers, device=dev, precision="bf16")
+            s2 = tm.GraphedTrainStep(m2, train.Adam(m2.parameters()), B, L, Lt)
+            for k in range(2):
+                s2(batch, alpha_set, k + 1)
+            sync()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                s2(batch, alpha_set, k + 3)
+            sync()
+            d2 = (time.perf_counter() - t1) / args.steps
+            res["bf16_mode"] = {"value": B / d2, "unit": "samples/s", "ms_per_step": d2 * 1e3, "steps": args.steps}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_train_baseline(args, spec)
         print(json.dumps(res), flush=True)

@@ -227,7 +227,7 @@ struct OpGemm {
   const float* B; long sbk, sbn, sbzo, sbzi, sbt; int b_shift, b_z_shift;
   float* C; long scm, scn, sczo, sczi;
   int M, N, K, nzo, nzi, lr, taps;
-  const float* bias; float alpha; int accumulate;
+  const float* bias; float alpha; int accumulate, bf16;
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
 hipError_t launch_film_table(int dir, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int TOT, float* film,

@@ -374,11 +374,24 @@ namespace {
 // — weight gradients contract over all B*L stroke rows into a few small tiles, and would otherwise run on a few CUs.
 constexpr int GT = 64, GK = 32, GS = 36;
 
-template <bool AM, bool BK, bool AV, bool BV>
+// TS = float: exact-f32 MFMA (the default: gradients match the reference's autograd to 1e-5).  TS = bf16_t: the operand tiles
+// are rounded to bf16 on their way into LDS and contracted with v_mfma_f32_16x16x32_bf16 (fp32 accumulation, fp32 operands
+// in memory, fp32 master weights) — mixed-precision training, 8x fewer MFMA instructions and half the LDS traffic per step.
+template <typename TS> constexpr int tile_row = sizeof(TS) == 4 ? GS : 48;   // elements; bf16: 96-byte rows ((stride / 16) mod 4 = 2, gemm_core.h)
+DHW_DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+DHW_DEV void st4(bf16_t* p, f32x4 v) {
+  bf16_t h[4] = {from_f<bf16_t>(v[0]), from_f<bf16_t>(v[1]), from_f<bf16_t>(v[2]), from_f<bf16_t>(v[3])};
+  *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(h);
+}
+DHW_DEV Frag<float> ld_frag(const float* p) { Frag<float> f; f.lo = *reinterpret_cast<const f32x4*>(p); f.hi = *reinterpret_cast<const f32x4*>(p + 4); return f; }
+DHW_DEV Frag<bf16_t> ld_frag(const bf16_t* p) { return frag_load(p); }
+
+template <bool AM, bool BK, bool AV, bool BV, typename TS>
 __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int tiles_n, int ksplit, int kslice) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * GT * GS];
-  float* As = smem;
-  float* Bs = smem + GT * GS;
+  constexpr int TR = tile_row<TS>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * GT * GS];      // operand tiles (TS), then the fp32 output tile
+  TS* As = reinterpret_cast<TS*>(smem);
+  TS* Bs = As + GT * TR;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
   int bx = blockIdx.x;
   const int ks = bx % ksplit; bx /= ksplit;
@@ -465,19 +478,19 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   auto stage = [&](const float (&ra)[8], const float (&rb)[8]) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      if constexpr (AV && !AM) *reinterpret_cast<f32x4*>(As + a_m(j) * GS + a_k(j)) = (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+      if constexpr (AV && !AM) st4(As + a_m(j) * TR + a_k(j), (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]});
       else if constexpr (AV) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) As[(a_m(j) + e) * GS + a_k(j)] = ra[4 * j + e];
-      } else As[a_m(j) * GS + a_k(j)] = ra[j];
+        for (int e = 0; e < 4; ++e) As[(a_m(j) + e) * TR + a_k(j)] = from_f<TS>(ra[4 * j + e]);
+      } else As[a_m(j) * TR + a_k(j)] = from_f<TS>(ra[j]);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if constexpr (BV && BK) *reinterpret_cast<f32x4*>(Bs + b_n(j) * GS + b_k(j)) = (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+      if constexpr (BV && BK) st4(Bs + b_n(j) * TR + b_k(j), (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]});
       else if constexpr (BV) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[(b_n(j) + e) * GS + b_k(j)] = rb[4 * j + e];
-      } else Bs[b_n(j) * GS + b_k(j)] = rb[j];
+        for (int e = 0; e < 4; ++e) Bs[(b_n(j) + e) * TR + b_k(j)] = from_f<TS>(rb[4 * j + e]);
+      } else Bs[b_n(j) * TR + b_k(j)] = from_f<TS>(rb[j]);
     }
   };
 
@@ -499,15 +512,11 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
         __syncthreads();        // the previous step's fragment reads are done
         stage(rar[p], rbr[p]);
         __syncthreads();
-        Frag<float> fa[2], fb[2];
+        Frag<TS> fa[2], fb[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const float* pa = As + (wm + 16 * a + i) * GS + 8 * q;
-          fa[a].lo = *reinterpret_cast<const f32x4*>(pa);
-          fa[a].hi = *reinterpret_cast<const f32x4*>(pa + 4);
-          const float* pb = Bs + (wn + 16 * a + i) * GS + 8 * q;
-          fb[a].lo = *reinterpret_cast<const f32x4*>(pb);
-          fb[a].hi = *reinterpret_cast<const f32x4*>(pb + 4);
+          fa[a] = ld_frag(As + (wm + 16 * a + i) * TR + 8 * q);
+          fb[a] = ld_frag(Bs + (wn + 16 * a + i) * TR + 8 * q);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -783,11 +792,12 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   static const bool novec = [] { const char* e = getenv("DHW_SGEMM_SCALAR"); return e && *e == '1'; }();
   if (novec) av = bv = false;
   using KFn = void (*)(const OpGemm, int, int, int);
-#define DHW_SG4(AM_, BK_) sgemm_tiled_kernel<AM_, BK_, false, false>, sgemm_tiled_kernel<AM_, BK_, false, true>, \
-                          sgemm_tiled_kernel<AM_, BK_, true, false>, sgemm_tiled_kernel<AM_, BK_, true, true>
-  static const KFn variants[16] = {DHW_SG4(false, false), DHW_SG4(false, true), DHW_SG4(true, false), DHW_SG4(true, true)};
+#define DHW_SG4(AM_, BK_, TS_) sgemm_tiled_kernel<AM_, BK_, false, false, TS_>, sgemm_tiled_kernel<AM_, BK_, false, true, TS_>, \
+                               sgemm_tiled_kernel<AM_, BK_, true, false, TS_>, sgemm_tiled_kernel<AM_, BK_, true, true, TS_>
+  static const KFn variants[32] = {DHW_SG4(false, false, float), DHW_SG4(false, true, float), DHW_SG4(true, false, float), DHW_SG4(true, true, float),
+                                   DHW_SG4(false, false, bf16_t), DHW_SG4(false, true, bf16_t), DHW_SG4(true, false, bf16_t), DHW_SG4(true, true, bf16_t)};
 #undef DHW_SG4
-  hipLaunchKernelGGL(variants[am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  hipLaunchKernelGGL(variants[(g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, tiles_n, ksplit, kslice);
   return hipGetLastError();
 }
 hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {

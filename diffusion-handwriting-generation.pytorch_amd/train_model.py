@@ -64,8 +64,9 @@ class Tape:
     """Forward ops append their backward closure; ``backward()`` replays them in reverse.  Every backward kernel ADDS into
     the input's gradient buffer (zero-initialised on first touch), which is how autograd's fan-in sums arise."""
 
-    def __init__(self, device):
+    def __init__(self, device, bf16: bool = False):
         self.dev = device
+        self.bf16 = int(bf16)   # GEMM operands rounded to bf16 inside the kernel (fp32 accumulation); everything else stays fp32
         self.lib = _lib.lib()
         self.main = torch.cuda.current_stream(device)
         self.st = _stream(device)
@@ -119,7 +120,7 @@ class Tape:
         d = _lib.GemmDesc(A.data_ptr() + a_off * _F, sam, sak, za[0], za[1], a_shift, a_tap_shift,
                           Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
-                          M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc))
+                          M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16)
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
@@ -355,8 +356,14 @@ class TrainModel:
 
     STYLE_DROP = 0.3   # text_style.py:88
 
-    def __init__(self, state_dict: dict, num_layers: int = 2, device=None, drop_rate: float = 0.0, seed: int = 0):
-        """``drop_rate``: the EncoderLayers' dropout (model.py:23; configs/best.yml trains with 0.0, the class default is 0.1)."""
+    def __init__(self, state_dict: dict, num_layers: int = 2, device=None, drop_rate: float = 0.0, seed: int = 0, precision: str = "fp32"):
+        """``drop_rate``: the EncoderLayers' dropout (model.py:23; configs/best.yml trains with 0.0, the class default is 0.1).
+        ``precision``: "fp32" — exact-f32 MFMA everywhere, the mode the gradient fixtures pin — or "bf16": mixed precision, every
+        GEMM (Linear / Conv1d / attention, forward and backward) contracts bf16-rounded operands with fp32 accumulation; weights,
+        activations in memory, gradients, optimizer state and all non-GEMM arithmetic stay fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         if not 0.0 <= drop_rate < 1.0:
             raise ValueError("drop_rate must be in [0, 1)")
         if not torch.cuda.is_available():
@@ -533,7 +540,7 @@ class TrainModel:
         B, L, _ = strokes.shape
         if L % 8:
             raise ValueError("the stroke length must be a multiple of 8 (three AvgPool1d(2) stages)")
-        t = self.tape = Tape(dev)
+        t = self.tape = Tape(dev, bf16=self.precision == "bf16")
         self._site = 3
         x_in, sig_in, sty = Var(strokes.view(B * L, 2), leaf=True), Var(sigma.view(B, 1), leaf=True), Var(style, leaf=True)
 

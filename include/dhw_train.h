@@ -88,6 +88,8 @@ typedef struct {
   float* C; long long scm, scn, sczo, sczi;
   int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate;
+  int bf16;   /* 0: exact-f32 MFMA.  1: the operands (fp32 in memory) are rounded to bf16 on their way into LDS and contracted on
+                 the bf16 MFMA with fp32 accumulation — mixed-precision training with fp32 master weights */
 } dhw_gemm_desc;
 
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
