@@ -25,6 +25,7 @@ namespace {
 // diagnostic builds only (-DDHW_ABL=n, tools/build_tools.sh): bit3 = SiLU -> identity, bit4 = no output / pool copy-out,
 // bit5 = x tile not loaded (zeros), bit6 = workgroup barriers removed (results are wrong; only the timing is read)
 #define CB_SILU(x) ((DHW_ABL & 8) ? (x) : silu_t<T>(x))
+#define CB_SILU_TILES(NT_, MT_, v) do { if constexpr (!(DHW_ABL & 8)) silu_tiles2<T, NT_, MT_>(v); } while (0)
 #define CB_BARRIER() do { if constexpr (!(DHW_ABL & 64)) lds_barrier(); } while (0)
 
 #define STAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0, (threadIdx.x >> 6) * 16 + slot, __builtin_amdgcn_s_memrealtime())
@@ -148,65 +149,69 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     // h rows [m0-3, m0-3+RH) are staged where h1/h2 will live later; the up-sampled low rows go straight into the XR
     // tile, and the GEMM epilogue adds the convolution in place (same lane reads and writes an element).
     constexpr int RXP = (RX + 15) / 16 * 16, RH = RXP + 2, MTU = RXP / 16;
-    constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 4, NTU = TU / WNU;   // (12 tiles: 4 waves, one per SIMD, 3 tiles each)
+    // Wave layout: channels over WNU waves; 12 channel tiles (dec1) would leave 4 of 8 waves idle through the whole stage,
+    // so there the rows are split over WMU = 2 row groups of MTG tiles (2 x 4 waves; the second group's surplus tile reads
+    // LDS rows past the staged ones and is discarded by the r < RX test below).
+    constexpr int TU = UPC / 16, WNU = TU % 8 == 0 ? 8 : 4, WMU = NW / WNU, NTU = TU / WNU;
+    constexpr int MTG = (MTU + WMU - 1) / WMU;
     static_assert(NTU * WNU == TU && NW == 8, "unsupported input width");
-    const bool actu = WNU == NW || wave < WNU;
-    const int ntu0 = (actu ? wave : 0) * NTU, nu = ntu0 * 16 + 4 * g;
+    const int wmu = wave / WNU, wnu = wave % WNU;
+    const int ntu0 = wnu * NTU, nu = ntu0 * 16 + 4 * g, rowu0 = wmu * MTG * 16;
     constexpr int UCH = up_skip_width<UPC>();
     const int Ch = SK ? UCH : p.up_cin, KCh = Ch / 32, SHh = tile_stride<T>(Ch);
     char* HS = H1;
-    WRing<T, NTU, (NTU * MTU >= 24 ? 12 : RING)> ringu;
+    WRing<T, NTU, (NTU * MTG >= 24 ? 12 : RING)> ringu;
     Epi<NTU> epu;
     {
-      const int cpr = Ch * ES / 16, cpx = Cin * ES / 16;
+      // both input tiles in ONE memory round trip: every load of the h rows and of the low rows is requested before the
+      // first LDS store, at clamped (always valid) addresses; rows outside the sample are zeroed by the store's select.
+      // (Two back-to-back staged copies with per-lane conditional loads cost two dependent round trips plus the
+      // s_waitcnt vmcnt(0) that hipcc puts at the join of every conditional load: 2.2-2.4 us of a 9-12 us stage, r2.)
+      constexpr int CPRH = UCH * ES / 16, CPX = UPC * ES / 16;
+      constexpr int UH = (RH * CPRH + NTHR - 1) / NTHR, UL = (RX * CPX + NTHR - 1) / NTHR;
+      static_assert(SK, "the fused input stage is compiled for static widths");
       const char* src = reinterpret_cast<const char*>(p.up_h);
       const char* low = reinterpret_cast<const char*>(p.up_low);
-      staged_copy<4>(RH * cpr, tid, NTHR,
-          [&](int id) { const int r = id / cpr, cc = id - r * cpr, lrow = m0 - 3 + r;
-                        return lrow >= 0 && lrow < p.L ? reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Ch) * ES + (size_t)cc * 16) : nullptr; },
-          [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(HS + r * SHh + cc * 16); });
-      staged_copy<4>(RX * cpx, tid, NTHR,
-          [&](int id) { const int r = id / cpx, cc = id - r * cpx, lrow = m0 - 2 + r;
-                        return lrow >= 0 && lrow < p.L ? reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * Cin) * ES + (size_t)cc * 16) : nullptr; },
-          [&](int id) { const int r = id / cpx, cc = id - r * cpx; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); });
+      CopyRegs<UH> ch;
+      CopyRegs<UL> cl;
+      ch.load(RH * CPRH, tid, NTHR, [&](int id) { const int r = id / CPRH, cc = id - r * CPRH, lrow = min(max(m0 - 3 + r, 0), p.L - 1);
+                                                  return reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * UCH) * ES + (size_t)cc * 16); });
+      cl.load(RX * CPX, tid, NTHR, [&](int id) { const int r = id / CPX, cc = id - r * CPX, lrow = min(max(m0 - 2 + r, 0), p.L - 1);
+                                                 return reinterpret_cast<const uint4*>(low + ((size_t)(b * (p.L / 2) + (lrow >> 1)) * UPC) * ES + (size_t)cc * 16); });
+      ch.store(RH * CPRH, tid, NTHR, [&](int id) { const int r = id / CPRH, cc = id - r * CPRH; return reinterpret_cast<uint4*>(HS + r * SHh + cc * 16); },
+               [&](int id) { const int lrow = m0 - 3 + id / CPRH; return lrow >= 0 && lrow < p.L; });
+      cl.store(RX * CPX, tid, NTHR, [&](int id) { const int r = id / CPX, cc = id - r * CPX; return reinterpret_cast<uint4*>(XR + r * SX + cc * 16); },
+               [&](int id) { const int lrow = m0 - 2 + id / CPX; return lrow >= 0 && lrow < p.L; });
     }
-    if (actu) {   // (requested behind the staging loads: see below)
-      if constexpr (SK) ringu.template fill_s<3 * UCH / 32>(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8);
-      else ringu.fill(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8, KCh * 3);
-      epu.load_bias(p.up_b, nu);
-    }
+    // (requested behind the staging loads: see below)
+    ringu.template fill_s<3 * UCH / 32>(reinterpret_cast<const T*>(p.up_w) + ((size_t)ntu0 * KCh * 3 * 64 + lane) * 8);
+    epu.load_bias(p.up_b, nu);
     CB_BARRIER();
     STAMP(10);
-    f32x4 acc[NTU][MTU];
+    f32x4 acc[NTU][MTG];
     acc_zero(acc);
-    if (actu) {
-      if constexpr (SK) ringu.template run_s<MTU, 3 * UCH / 32>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
-      else ringu.template run<MTU>(acc, HS + l15 * SHh + g * 8 * ES, SHh, KCh);
-    }
+    ringu.template run_s<MTG, 3 * UCH / 32>(acc, HS + (rowu0 + l15) * SHh + g * 8 * ES, SHh, KCh);
     STAMP(11);
     if (act1) {
       fill1();   // flies during the epilogue
       ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
     }
-    if (actu) {
+    {
+      // x = round(conv + bias + low) (the block's own 'same' padding: zero outside the sample) -> XR; SiLU(x) -> XS
+      auto keep = [&](int j) { const int lrow = m0 - 2 + rowu0 + j * 16 + l15; return lrow >= 0 && lrow < p.L; };
+      auto valid = [&](int j) { return rowu0 + j * 16 + l15 < RX; };
 #pragma unroll
       for (int i = 0; i < NTU; ++i)
 #pragma unroll
-        for (int j = 0; j < MTU; ++j) {
-          const int r = j * 16 + l15;
-          const int lrow = m0 - 2 + r;
-          if (r < RX) {
-            T* xp = reinterpret_cast<T*>(XR + r * SX) + nu + 16 * i;
-            f32x4 v = acc[i][j] + epu.bias[i] + load4(xp), sv;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              v[k] = (lrow >= 0 && lrow < p.L) ? to_f(from_f<T>(v[k])) : 0.f;   // the block's own 'same' padding
-              sv[k] = CB_SILU(v[k]);
-            }
-            store4(xp, v);
-            store4(reinterpret_cast<T*>(XS + r * SX) + nu + 16 * i, sv);
-          }
+        for (int j = 0; j < MTG; ++j) {
+          const int r = min(rowu0 + j * 16 + l15, RX - 1);   // (clamped: rows past RX are computed but never stored)
+          acc[i][j] = round_to<T>(acc[i][j] + epu.bias[i] + load4(reinterpret_cast<const T*>(XR + r * SX) + nu + 16 * i));
         }
+      // (a 16-byte store covers the partner lane's `low` values too: its data depends, through the lane swap, on both lanes'
+      // loads of the pair, so no store can be issued ahead of them)
+      store_tiles<T, NTU, MTG>(XR, SX, rowu0, nu, acc, keep, valid);
+      CB_SILU_TILES(NTU, MTG, acc);
+      store_tiles<T, NTU, MTG>(XS, SX, rowu0, nu, acc, keep, valid);
     }
     STAMP(12);
   } else if (p.strokes) {
@@ -228,31 +233,33 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
       store4(reinterpret_cast<T*>(XS + r * SX) + c, sv);
     }
   } else {
+    // x tile: every load is requested (clamped, always valid address) before the first use; rows outside the sample are
+    // zeroed by a select.  (Per-lane conditional loads compile to branches with s_waitcnt vmcnt(0) at their joins.)
     const int cpr = Cin * ES / 16;
     const int total = RX * cpr;
     const char* src = reinterpret_cast<const char*>(p.x);
     constexpr int U = 4;
     for (int base = tid; base < total; base += NTHR * U) {
       uint4 v[U];
-      int dst[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int id = base + u * NTHR;
+        const int id = min(base + u * NTHR, total - 1);
         const int r = id / cpr, cc = id - r * cpr;
-        const int lrow = m0 - 2 + r;
-        v[u] = make_uint4(0, 0, 0, 0);
-        dst[u] = id < total ? r * SX + cc * 16 : -1;
-        if (id < total && lrow >= 0 && lrow < p.L && !(DHW_ABL & 32))
-          v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Cin) * ES + (size_t)cc * 16);
+        const int lrow = min(max(m0 - 2 + r, 0), p.L - 1);
+        if constexpr (DHW_ABL & 32) v[u] = make_uint4(0, 0, 0, 0);
+        else v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.L + lrow) * Cin) * ES + (size_t)cc * 16);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (dst[u] < 0) continue;
-        *reinterpret_cast<uint4*>(XR + dst[u]) = v[u];
-        T* e = reinterpret_cast<T*>(&v[u]);
-#pragma unroll
-        for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(CB_SILU(to_f(e[i])));
-        *reinterpret_cast<uint4*>(XS + dst[u]) = v[u];
+        const int id = base + u * NTHR;
+        if (id < total) {
+          const int r = id / cpr, cc = id - r * cpr;
+          const int lrow = m0 - 2 + r;
+          const bool k = lrow >= 0 && lrow < p.L;
+          uint4 w = make_uint4(k ? v[u].x : 0u, k ? v[u].y : 0u, k ? v[u].z : 0u, k ? v[u].w : 0u);
+          *reinterpret_cast<uint4*>(XR + r * SX + cc * 16) = w;
+          *reinterpret_cast<uint4*>(XS + r * SX + cc * 16) = (DHW_ABL & 8) ? w : silu_piece<T>(w);
+        }
       }
     }
   }
@@ -278,22 +285,25 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
       else ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
     }
     STAMP(2);
-    if (act2) {
-      ring2.template fill_s<(C1 / 32) * 3>(reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * (C1 / 32) * 3 * 64 + lane) * 8);
-      ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2);
-    }
+    // epilogue of conv1, tile pair by tile pair, with the conv2 weight prefetch requested between the pairs
+    constexpr int KT2 = (C1 / 32) * 3;
+    const T* w2 = reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * KT2 * 64 + lane) * 8;
+    if (act2) { ring2.template fill_begin<KT2>(w2); ep2.load(p.b_c2, gam + p.f2, bet + p.f2, n2); }
+    constexpr int ST1 = epilogue_steps<NT1, MT1>(), CH2 = decltype(ring2)::template fill_chunks<KT2>(), PER1 = (CH2 + ST1 - 1) / ST1;
     if (act1) {
+      epilogue_pairs<T, NT1, MT1, !(DHW_ABL & 8)>(H1, SH1, row01, n1, acc,
+          [&](int i, const f32x4& a) { return (a + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i]; },
+          [&](int j) { const int srow = m0 - 1 + row01 + j * 16 + l15; return srow >= 0 && srow < p.L; },   // conv2 pads h1 with zeros
+          [](int) { return true; },
+          [&](int step) {
+            if (act2) {
 #pragma unroll
-      for (int i = 0; i < NT1; ++i)
+              for (int c = 0; c < PER1; ++c) ring2.template fill_chunk<KT2>(step * PER1 + c);
+            }
+          });
+    } else if (act2) {
 #pragma unroll
-        for (int j = 0; j < MT1; ++j) {
-          const int r = row01 + j * 16 + l15;
-          const int srow = m0 - 1 + r;
-          f32x4 v = (acc[i][j] + ep1.bias[i]) * ep1.gam[i] + ep1.bet[i];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = (srow >= 0 && srow < p.L) ? CB_SILU(v[k]) : 0.f;   // conv2 pads h1 with zeros
-          store4(reinterpret_cast<T*>(H1 + r * SH1) + n1 + 16 * i, v);
-        }
+      for (int c = 0; c < CH2; ++c) ring2.template fill_chunk<KT2>(c);
     }
     // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
     for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
@@ -309,16 +319,18 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
     acc_zero(acc);
     ring2.template run_s<MT2, (C1 / 32) * 3>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
     STAMP(4);
-    ring2.template fill_s<CO / 32>(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * (CO / 32) * 64 + lane) * 8);
+    {
+      constexpr int KTF = CO / 32;
+      ring2.template fill_begin<KTF>(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * KTF * 64 + lane) * 8);
+      constexpr int ST2 = epilogue_steps<NT2, MT2>(), CHF = decltype(ring2)::template fill_chunks<KTF>(), PER2 = (CHF + ST2 - 1) / ST2;
+      epilogue_pairs<T, NT2, MT2, !(DHW_ABL & 8)>(H2, SH2, row02, n2, acc,
+          [&](int i, const f32x4& a) { return (a + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i]; },
+          [](int) { return true; }, [](int) { return true; },
+          [&](int step) {
 #pragma unroll
-    for (int i = 0; i < NT2; ++i)
-#pragma unroll
-      for (int j = 0; j < MT2; ++j) {
-        f32x4 v = (acc[i][j] + ep2.bias[i]) * ep2.gam[i] + ep2.bet[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = CB_SILU(v[k]);
-        store4(reinterpret_cast<T*>(H2 + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, v);
-      }
+            for (int c = 0; c < PER2; ++c) ring2.template fill_chunk<KTF>(step * PER2 + c);
+          });
+    }
     ep2.load(p.b_fc, gam + p.f3, bet + p.f3, n2);
   }
   STAMP(14);
@@ -386,8 +398,8 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
 #pragma unroll
       for (int i = 0; i < NT2; ++i)
 #pragma unroll
-        for (int j = 0; j < MT2; ++j)
-          store4(reinterpret_cast<T*>(smem + (row02 + j * 16 + l15) * SH2) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
+        for (int j = 0; j < MT2; ++j) acc[i][j] += ep2.bias[i];
+      store_tiles<T, NT2, MT2>(smem, SH2, row02, n2, acc);
     }
     CB_BARRIER();
     if constexpr (!(DHW_ABL & 16))
@@ -415,7 +427,10 @@ size_t lds_bytes(int Cin, int up_cin = 0) {
   const size_t xt = (size_t)2 * (BM + 2) * tile_stride<T>(Cin);
   const size_t ops = xt + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * h2_stride<T, BM>(CO);
   const size_t outf = (size_t)BM * (CO * 4 + 16);
-  const size_t up = up_cin ? xt + (size_t)((BM + 2 + 15) / 16 * 16 + 2) * tile_stride<T>(up_cin) : 0;   // x tiles + staged h rows
+  // x tiles + staged h rows (with 12 channel tiles the input GEMM runs as 2 row groups of ceil(MTU / 2) tiles: the second
+  // group's surplus tile reads rows past the staged ones, which must still lie inside the allocation)
+  const int mtu = (BM + 2 + 15) / 16, wmu = (Cin / 16) % 8 == 0 ? 1 : 2, rows_read = wmu * ((mtu + wmu - 1) / wmu) * 16 + 2;
+  const size_t up = up_cin ? xt + (size_t)rows_read * tile_stride<T>(up_cin) : 0;
   return std::max(ops, std::max(outf, up));
 }
 

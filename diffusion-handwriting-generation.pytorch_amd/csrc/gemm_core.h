@@ -3,6 +3,7 @@
 // LDS tile geometry, and the cross-wave LayerNorm.
 #pragma once
 #include "dhw_common.h"
+#include "epilogue.h"
 
 // An activation tile in LDS: `rows` rows of C elements, row stride padded by 16 bytes so the
 // 16-lane fragment reads (row = lane&15, 16-byte column slot = lane>>4) spread over the banks.
@@ -23,10 +24,10 @@ DHW_DEV void keep_alive(const Frag<float>& f) { asm volatile("" ::"v"(f.lo), "v"
 #ifndef DHW_ABL
 #define DHW_ABL 0   // diagnostic builds only (-DDHW_ABL=n): default ablation mask of every main loop
 #endif
-template <typename T, int NT, int RING = (sizeof(T) == 2 ? 24 : 12)>
+template <typename T, int NT, int RING = (sizeof(T) == 2 ? 24 : 12), int DMAX = 8>
 struct WRing {
   static constexpr int D0 = RING / NT;
-  static constexpr int D = D0 < 2 ? 2 : (D0 > 8 ? 8 : D0);   // ~RING fragments (1 KiB each for bf16) in flight per wave
+  static constexpr int D = D0 < 2 ? 2 : (D0 > DMAX ? DMAX : D0);   // ~RING fragments (1 KiB each for bf16) in flight per wave
   Frag<T> q[D][NT];
   const T* base;
   int KT, KTS;
@@ -97,6 +98,23 @@ struct WRing {
   DHW_DEV void load_chunk(int d, int k) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) q[d][i] = frag_load(base + ((size_t)i * KTS + k) * 512);
+  }
+  // fill_s in two parts: fill_begin() does the bookkeeping, fill_chunk<KT_>(d) requests ring slot d (no-op past the stage's
+  // chunks / the ring depth).  Issuing a vector-memory instruction blocks the wave until the CU's L1 path accepts it, and
+  // that path moves 64 B/clk for the whole CU: a wave that requests its whole ring at once is stuck in instruction issue for
+  // (ring bytes of all 8 waves) / 64 B/clk — 0.7-1.3 us per stage boundary (per-wave stamps, r3) — and its epilogue VALU work
+  // waits behind that.  Requested one chunk at a time between pieces of the epilogue, the two overlap.
+  template <int KT_>
+  DHW_DEV void fill_begin(const T* __restrict__ wbase, int kts = 0) {
+    base = wbase;
+    KT = KT_;
+    KTS = kts ? kts : KT_;
+  }
+  template <int KT_>
+  static constexpr int fill_chunks() { return D < KT_ ? D : KT_; }
+  template <int KT_>
+  DHW_DEV void fill_chunk(int d) {   // d: compile-time constant after unrolling
+    if (d < fill_chunks<KT_>()) load_chunk(d, d);
   }
   template <int KT_>
   DHW_DEV void fill_s(const T* __restrict__ wbase, int kts = 0) {
