@@ -70,8 +70,7 @@ DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int 
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xg_max(mx);
     const float m_new = fmaxf(m_run, mx);       // finite: every block has >= 1 real key
     const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first block
     float psum = 0.f;
@@ -96,8 +95,7 @@ DHW_DEV void attn_wave16(const Frag<T> (&qf)[(D + 31) / 32], const T* krow, int 
     }
   }
   float l = l_run;
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
+  l = xg_sum(l);
   const float inv = 1.0f / l;
 #pragma unroll
   for (int t = 0; t < DT; ++t) o[t] = o[t] * inv;
@@ -155,8 +153,7 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
       s[t][r] = v;
       mx = fmaxf(mx, v);
     }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  mx = xg_max(mx);
   const float m_new = fmaxf(m_run, mx);
   const float alpha = __expf(m_run - m_new);
   float psum = 0.f;
@@ -180,6 +177,138 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
     for (int pp = 0; pp < NPF; ++pp) {
       const T* vp = reinterpret_cast<const T*>(vt + (16 * t) * SV) + 32 * pp;
       mma32(o[t], frag_load_halves(vp, vp + 16), pf[pp]);
+    }
+  }
+}
+
+// bf16 form of attn_block_lds with the softmax arithmetic trimmed, for NU independent (16 rows x 1 head) units at once:
+//   * scores are scaled once by c = log2(e) / sqrt(D) (packed multiplies) and the running maximum is kept in those units, so
+//     the exponential is exp2(u - m): one packed subtract + v_exp per score.  (Folding the scale into an fma in front of the
+//     exponential is one instruction shorter but NOT robust: fma(s, c, -round(m c)) of the maximum itself is the rounding
+//     residue of m c, which exceeds 1 once |m c| > 2^24 — the long-schedule stress test reaches that — and alpha computed from
+//     a re-multiplied m_run changed with hipcc's CSE / contraction choices per instantiation, which broke shard invariance.)
+//   * keys past Lk are masked only in the block that contains Lk (wave-uniform test), the padding mask only when MASKED
+//     (cross-attention): -1e9 in score units = -1e9 log2(e) in scaled units;
+//   * row maxima with v_max3_f32, lane-group reductions with v_permlane swaps (xg_max) instead of ds_bpermute;
+//   * the O rescale is skipped in the first block (O = 0);
+//   * the units' phases are written unit-interleaved (all QK^T MFMAs, all maxima, all exponentials, all PV MFMAs): a wave
+//     that owns two heads overlaps one unit's MFMAs with the other's VALU work instead of running two serial chains.
+// The fp32 parity mode keeps attn_block_lds (exact reference operation order).
+#ifndef DHW_ATT_ABL
+#define DHW_ATT_ABL 0   // diagnostic builds only: bit0 = no MFMAs, bit1 = no exponentials, bit2 = no LDS operand reads, bit3 = no max / rescale
+#endif
+template <int D, int KB, bool MASKED, int NU>
+DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char* const (&kt)[NU], int SK, const char* const (&vt)[NU], int SV, int kb,
+                             unsigned padbits, int Lk, float (&m_run)[NU], float (&l_run)[NU], f32x4 (*o)[D / 16]) {
+  typedef bf16_t T;
+  constexpr int DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
+  static_assert(D % 32 == 0, "head width");
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const float c = rsqrtf((float)D) * 1.4426950408889634f;
+  f32x4 s[NU][NTILE];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      s[u][t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int ch = 0; ch < KCH; ++ch)
+      {
+        const Frag<T> kf = (DHW_ATT_ABL & 4) ? qf[u][ch] : frag_load(reinterpret_cast<const T*>(kt[u] + t * 16 * SK) + 32 * ch + 8 * g);
+        if constexpr (DHW_ATT_ABL & 1) { asm volatile("" ::"v"(kf.v)); s[u][t][ch] += (float)kf.v[0]; }
+        else mma32(s[u][t], kf, qf[u][ch]);
+      }
+    }
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) s[u][t] = s[u][t] * c;
+  if (kb + KB > Lk) {   // (wave-uniform) the block that holds the end of the sequence
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[u][t][r] = kb + 16 * t + 4 * g + r < Lk ? s[u][t][r] : -INFINITY;
+  }
+  if constexpr (MASKED) {
+    const float neg = -1e9f * 1.4426950408889634f;   // attention.py:44, in scaled units
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[u][t][r] += ((padbits >> (4 * t + r)) & 1u) ? neg : 0.f;
+  }
+  float m_new[NU], alpha[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    float mx = fmaxf(fmaxf(s[u][0][0], s[u][0][1]), fmaxf(s[u][0][2], s[u][0][3]));
+#pragma unroll
+    for (int t = 1; t < NTILE; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[u][t][0], s[u][t][1])), fmaxf(s[u][t][2], s[u][t][3]));
+    m_new[u] = (DHW_ATT_ABL & 8) ? 0.f : fmaxf(m_run[u], xg_max(mx));   // finite: every block has >= 1 real key
+    alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new[u]);   // exp2(-inf) = 0 in the first block
+    m_run[u] = m_new[u];
+  }
+  Frag<T> pf[NU][NPF];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    f32x4 psum = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      s[u][t] = s[u][t] - m_new[u];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[u][t][r] = (DHW_ATT_ABL & 2) ? s[u][t][r] : __builtin_amdgcn_exp2f(s[u][t][r]);
+      psum += s[u][t];
+    }
+    l_run[u] = __builtin_fmaf(l_run[u], alpha[u], (psum[0] + psum[1]) + (psum[2] + psum[3]));
+#pragma unroll
+    for (int pp = 0; pp < NPF; ++pp) frag_from_f32(pf[u][pp], s[u][2 * pp], s[u][2 * pp + 1]);
+  }
+  if (kb != 0) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) o[u][t] = o[u][t] * alpha[u];
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int pp = 0; pp < NPF; ++pp) {
+        const T* vp = reinterpret_cast<const T*>(vt[u] + (16 * t) * SV) + 32 * pp;
+        const Frag<T> vf = (DHW_ATT_ABL & 4) ? pf[u][pp] : frag_load_halves(vp, vp + 16);
+        if constexpr (DHW_ATT_ABL & 1) { asm volatile("" ::"v"(vf.v)); o[u][t][pp] += (float)vf.v[0]; }
+        else mma32(o[u][t], vf, pf[u][pp]);
+      }
+}
+// One KB-key block for the UMAX (1 or 2) units of a wave: unit u = head hs + u * HS, active when that head exists (the
+// second unit of a wave may not).  kt0 / vt0: this lane's LDS addresses for head 0 (K tile row lane & 15; V^T tile row
+// lane & 15, key 4 (lane >> 4)); head h lies h * 64 channels further in both tiles.
+template <typename T, int KB, bool MASKED, int UMAX>
+DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, const char* vt0, int SV, int hs, int HS, int H, int kb,
+                        unsigned padbits, int Lk, float (&mr)[UMAX], float (&lr)[UMAX], f32x4 (&o)[UMAX][4]) {
+  constexpr int ES = sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    // (both units of a two-head wave in ONE straight-line block — NU = 2 — measured slower: 27.4 vs 26.4 us for the d = 192
+    // layer; the LDS operand reads, not the dependent chains, bound this stage: profiles/r03_attention_ablation.log)
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      if (h < H) {
+        const char* const kt[1] = {kt0 + h * 64 * ES};
+        const char* const vt[1] = {vt0 + h * 64 * SV};
+        float m1[1] = {mr[u]}, l1[1] = {lr[u]};
+        attn_block_bf16<64, KB, MASKED, 1>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        mr[u] = m1[0]; lr[u] = l1[0];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      if (h < H) attn_block_lds<T, 64, KB>(qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
     }
   }
 }

@@ -162,6 +162,22 @@ struct CopyRegs {
   }
 };
 
+// Reductions over the 4 lane groups g = lane >> 4 of a wave (lanes with equal lane & 15): every lane ends with the result.
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers inside the VALU; __shfl_xor
+// is a ds_bpermute_b32, i.e. an LDS-pipe round trip (~100 cycles) on the serial chain of every softmax block and LayerNorm.
+DHW_DEV float xg_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+DHW_DEV float xg_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory queue
 // (s_waitcnt vmcnt(0)), which would stall every wave until the NEXT stage's prefetched weight fragments have
 // landed; the fused kernels exchange data between waves through LDS only, so lgkmcnt(0) + s_barrier suffices

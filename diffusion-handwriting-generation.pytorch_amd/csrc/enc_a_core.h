@@ -194,13 +194,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
         attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
       }
-#pragma unroll
-      for (int u = 0; u < UMAX; ++u) {
-        const int h = hs + u * HS;
-        if (h < H)
-          attn_block_lds<T, 64, KBC>(qf[u], KT + l15 * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + 4 * g * ES, SV, kb, padbits,
-                                     p.Lt, mr[u], lr[u], o[u]);
-      }
+      attn_units<T, KBC, true, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV + 4 * g * ES, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
       if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
                                              // barrier behind the a1 store below does)
     }
@@ -208,8 +202,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
       float l = lr[u];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
+      l = xg_sum(l);
       const float inv = 1.0f / l;
       if (h < H) {
         T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;

@@ -39,18 +39,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   enc_a_body<T, DM, BM>(p, m, b, m0, min(BM, p.Lk - m0));
 }
 
-// keys per staged self-attention block: 128 when K [keys][DM] + V^T [DM][keys] fit beside the a2 tile (they overlay the
-// x3 / FFN tiles, which are written only after the attention), else 64
+// Self-attention K / V staging.  bf16: 64-key blocks, DOUBLE buffered when two blocks of K [keys][DM] + V^T [DM][keys] fit
+// beside the a2 tile (they overlay the x3 / FFN tiles, which are written only after the attention): the next block's
+// global loads are in flight during the current block's softmax / MFMA work and only their LDS stores remain afterwards.
+// (Single-buffered 128-key blocks spent as long in the two dependent copy round trips per block as in the math:
+// profiles/r03_head_enclayer_stage_stamps.log, d = 192: staged 2.7 / 2.0 us, computed 3.3 / 3.3 us.)
+// fp32 parity mode: single-buffered 32-key blocks (its tiles are twice as wide).
 template <typename T, int DM, int BM>
-constexpr size_t self_att_bytes(int kbs) { return (size_t)BM * tile_stride<T>(DM) + (size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + 16); }
+constexpr size_t self_att_bytes(int kbs, int nbuf) { return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + 16)); }
 template <typename T, int DM, int BM>
-constexpr int self_kbs() {   // (32 keys: the fp32 parity mode, whose tiles are twice as wide)
-  return self_att_bytes<T, DM, BM>(128) <= 160 * 1024 ? 128 : (self_att_bytes<T, DM, BM>(64) <= 160 * 1024 ? 64 : 32);
-}
+constexpr int self_kbs() { return sizeof(T) == 2 ? 64 : 32; }
+template <typename T, int DM, int BM>
+constexpr bool self_db() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, 2) <= 160 * 1024; }
 template <typename T, int DM, int BM>
 constexpr size_t lds_bc_bytes() {
-  constexpr size_t S = tile_stride<T>(DM), KBS = self_kbs<T, DM, BM>();
-  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = BM * S + KBS * S + DM * (KBS * sizeof(T) + 16);
+  constexpr size_t S = tile_stride<T>(DM);
+  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = self_att_bytes<T, DM, BM>(self_kbs<T, DM, BM>(), self_db<T, DM, BM>() ? 2 : 1);
   return stages > att ? stages : att;
 }
 
@@ -95,11 +99,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 40, __builtin_amdgcn_s_memtime());
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
+    constexpr bool DB = self_db<T, DM, BM>();
     constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + 16;
-    char* KT = R2;
-    char* VT = KT + KBS * SK;
+    constexpr int BUFB = KBS * SK + DM * SV;   // one staged block: K tile, then V^T tile
     const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
+    const T* ksrc = qk + (size_t)b * p.Lk * 2 * DM + DM;
+    const T* vsrc = reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX;
+    constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBS / EPV;
+    constexpr int UK = (KBS * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
+    CopyRegs<UK> ck;
+    CopyRegs<UV> cv;
+    // K rows [kb, kb + KBS) x DM channels and V^T rows [0, DM) x keys [kb, kb + KBS): requested at clamped (valid) addresses;
+    // K rows at or past Lk and V^T pieces past lpadX are zero-filled by the store
+    auto request = [&](int kb) {
+      ck.load(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                                 return reinterpret_cast<const uint4*>(ksrc + (size_t)min(kb + r, p.Lk - 1) * 2 * DM + cc * EPV); });
+      cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                                                return reinterpret_cast<const uint4*>(vsrc + (size_t)ch * p.lpadX + (kb + (part + 1) * EPV <= p.lpadX ? kb + part * EPV : 0)); });
+    };
+    auto commit = [&](int kb, char* KT, char* VT) {
+      ck.store(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SK + cc * 16); },
+               [&](int id) { return kb + id / CPR < p.Lk; });
+      cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SV + part * 16); },
+               [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
+    };
     Frag<T> qf[UMAX][2];
     float mr[UMAX], lr[UMAX];
     f32x4 o[UMAX][4];
@@ -114,33 +138,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
     }
-    for (int kb = 0; kb < p.Lk; kb += KBS) {
-      attn_stage_kv<T, KBS>(KT, SK, VT, SV, qk + (size_t)b * p.Lk * 2 * DM + DM, 2 * DM,
-                            reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX, p.lpadX, DM, kb, p.Lk, tid, 512);
-      lds_barrier();
-      if (kb < 3 * KBS) STAMP(26 + 2 * (kb / KBS));
-#pragma unroll
-      for (int u = 0; u < UMAX; ++u) {
-        const int h = hs + u * HS;
-        if (h < H) {
-          constexpr int SUB = KBS < 64 ? KBS : 64;
-#pragma unroll
-          for (int sub = 0; sub < KBS; sub += SUB)
-            if (kb + sub < p.Lk)
-              attn_block_lds<T, 64, SUB>(qf[u], KT + (sub + l15) * SK + h * 64 * ES, SK, VT + (h * 64 + l15) * SV + (sub + 4 * g) * ES, SV,
-                                         kb + sub, 0u, p.Lk, mr[u], lr[u], o[u]);
+    request(0);   // (one round trip together with the q fragments)
+    commit(0, R2, R2 + KBS * SK);
+    lds_barrier();
+    int ib = 0;
+    for (int kb = 0; kb < p.Lk; kb += KBS, ++ib) {
+      const bool more = kb + KBS < p.Lk;
+      char* KT = R2 + (DB && (ib & 1) ? BUFB : 0);
+      char* VT = KT + KBS * SK;
+      char* KN = R2 + (DB && !(ib & 1) ? BUFB : 0);   // where the next block goes
+      if (DB && more) request(kb + KBS);
+      if (ib < 3) STAMP(26 + 2 * ib);
+      attn_units<T, KBS, false, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV + 4 * g * ES, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
+      if (ib < 3) STAMP(27 + 2 * ib);
+      if (more) {
+        if (!DB) {          // single buffer: every wave must be past its reads before the tiles are rewritten
+          lds_barrier();
+          request(kb + KBS);
         }
+        commit(kb + KBS, KN, KN + KBS * SK);
+        lds_barrier();      // next block complete (double buffer: its previous contents were read one iteration ago)
       }
-      if (kb < 3 * KBS) STAMP(27 + 2 * (kb / KBS));
-      if (kb + KBS < p.Lk) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
-                                             // barrier behind the a2 store below does)
+      // (after the last block the barrier behind the a2 store below separates the staging tiles from their next use)
     }
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
       float l = lr[u];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
+      l = xg_sum(l);
       const float inv = 1.0f / l;
       if (h < H) {
         T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;

@@ -232,8 +232,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NT; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = xg_sum(s);
     if (g == 0 && act) red[wn * ROWS + row0 + j * 16 + l15] = s;
   }
   lds_barrier();
@@ -252,8 +251,7 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = xg_sum(s);
     if (g == 0 && act) red[(WN + wn) * ROWS + row0 + j * 16 + l15] = s;
   }
   lds_barrier();
@@ -283,8 +281,7 @@ DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s += acc[i][j][r]; q += acc[i][j][r] * acc[i][j][r]; }
-    s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    s = xg_sum(s); q = xg_sum(q);
     if (g == 0 && act) {
       red[wn * ROWS + row0 + j * 16 + l15] = s;
       red[(WN + wn) * ROWS + row0 + j * 16 + l15] = q;
