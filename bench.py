@@ -15,8 +15,11 @@ for the barrier and the max-over-ranks of the wall time; the sampling loop has n
 Prompt shards are independent (rank r samples the global prompts [r*B, (r+1)*B)) => weak scaling.
 
 Prints ONE JSON line (see the driver contract) with extra objects:
-  roofline     — for the dominant kernel class: algorithmic FLOPs and bytes per launch over the mean
-                 launch duration measured with HIP events on the launch stream (library profile mode)
+  roofline     — for the dominant kernel FUNCTION (launch labels grouped as rocprofv3 groups them): algorithmic FLOPs and
+                 bytes per launch over the mean launch duration measured with HIP events on the launch stream (library
+                 profile mode); `all_stroke_kernels` = the time-weighted figure over every fused stroke-side kernel
+  nl4_mode     — the same workload at the class-default depth num_layers=4 (N=1 only)
+  train_step   — a short run of the configs[4] training step (N=1 only; `--train` is the full measurement)
   cpu_baseline — the oracle (CPU restatement of the reference, kind "port") timed on this box's host
                  cores on a bounded sample of the same workload (rank 0, N=1 only)
   fp32_mode    — the same workload through the library's fp32 parity mode (N=1 only)
@@ -57,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the other-precision throughput figure (fp32_mode; bf16_mode with --train)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the short configs[4] training-step figure (train_step) in the default line")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="concurrent prompt sub-batches per GPU (0 = library default)")
     # launcher / distributed plumbing rehearsal on CPU (tests/test_bench_launcher_cpu.py): gloo, no GPU, no library
@@ -252,7 +256,13 @@ def worker(args):
             if not args.no_kernel_profile:
                 res["roofline"], res["kernels"] = kernel_profile(model, one_step)
             if world == 1 and not args.no_fp32 and args.precision == "bf16":
-                res["fp32_mode"] = fp32_mode(args, dev, text, style)
+                res["fp32_mode"] = other_mode(args, dev, text, style, precision="fp32", num_layers=args.num_layers)
+                if args.num_layers != 4:   # the class default depth (model.py:66; SURVEY 8: "report both, primary = 2")
+                    res["nl4_mode"] = other_mode(args, dev, text, style, precision="bf16", num_layers=4)
+            if world == 1 and not args.no_train_step:
+                del model
+                torch.cuda.empty_cache()
+                res["train_step"] = train_step_figure(args, dev)
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args, spec)
         print(json.dumps(res), flush=True)
@@ -267,7 +277,7 @@ def train_worker(args, dev, dist, rank, world):
     import numpy as np
     import torch
     from dhg_amd import spec, train, train_model as tm
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.set_num_threads(host_cores())   # (the cgroup share, not os.cpu_count(): oversubscribing it made the host the bottleneck)
     B, L, Lt = args.batch, args.L, args.Lt
     sd = spec.synthetic_state_dict(args.num_layers, 128, 192, 256, seed=0)
     model = tm.TrainModel(sd, num_layers=args.num_layers, device=dev, precision=args.precision)
@@ -385,8 +395,14 @@ def cpu_train_baseline(args, spec):
             "sample": f"forward + loss + backward of {B} samples (L={L}, Lt={Lt}) through the CPU oracle under torch autograd, best of 3"}
 
 
+KERNEL_FUNCTION = {"enc.fused_bc": "enc_bc_kernel", "enc.fused_bc+a": "enc_bc_kernel", "enc.fused_a": "enc_a_kernel",
+                   "convblock.fused": "convblock_kernel"}   # library launch label -> __global__ function (what rocprofv3 reports)
+
+
 def kernel_profile(model, one_step):
-    """One un-timed pass with every launch bracketed by HIP events on the launch stream."""
+    """One un-timed pass with every launch bracketed by HIP events on the launch stream.  Launch labels are grouped by
+    kernel FUNCTION (as the rocprofv3 kernel trace groups them): `roofline` is for the function with the largest share of the
+    GPU time; `roofline["all_stroke_kernels"]` is the time-weighted figure over every fused stroke-side kernel."""
     import torch
     model.profile(True)
     one_step(10_000)
@@ -399,9 +415,16 @@ def kernel_profile(model, one_step):
     for r in sorted(rows, key=lambda r: -r["total_ms"]):
         us = r["total_ms"] * 1e3 / r["launches"]
         fl, by = r["flops"] / r["launches"], r["bytes"] / r["launches"]
-        table.append({"label": r["label"], "launches": r["launches"], "share": r["total_ms"] / total, "avg_us": us,
+        table.append({"label": r["label"], "function": KERNEL_FUNCTION.get(r["label"], r["label"]), "launches": r["launches"],
+                      "share": r["total_ms"] / total, "avg_us": us,
                       "tflops": fl / us / 1e6 if us else 0.0, "gbs": by / us / 1e3 if us else 0.0})
-    dom = next(r for r in sorted(rows, key=lambda r: -r["total_ms"]) if r["flops"] > 0)
+    groups = {}
+    for r in rows:
+        g = groups.setdefault(KERNEL_FUNCTION.get(r["label"], r["label"]), {"total_ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "labels": []})
+        for k in ("total_ms", "launches", "flops", "bytes"):
+            g[k] += r[k]
+        g["labels"].append(r["label"])
+    name, dom = max(((k, g) for k, g in groups.items() if g["flops"] > 0), key=lambda kg: kg[1]["total_ms"])
     us = dom["total_ms"] * 1e3 / dom["launches"]
     fl, by = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
     t_mfma, t_hbm = fl / (PEAK_BF16_TFLOPS * 1e6), by / (PEAK_HBM_GBS * 1e3)   # us at the two roofs
@@ -410,9 +433,17 @@ def kernel_profile(model, one_step):
     else:
         roof = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof.update({"traffic": pmc_traffic(dom["label"]), "kernel": dom["label"], "avg_launch_us": us, "launches": dom["launches"],
+    stroke = [g for k, g in groups.items() if k in set(KERNEL_FUNCTION.values())]
+    s_ms, s_fl, s_by = (sum(g[k] for g in stroke) for k in ("total_ms", "flops", "bytes"))
+    roof.update({"traffic": pmc_traffic(name), "kernel": name, "labels": sorted(dom["labels"]), "avg_launch_us": us, "launches": dom["launches"],
                  "flops_per_launch": fl, "bytes_per_launch": by, "mfma_tflops": fl / us / 1e6, "hbm_gbs": by / us / 1e3,
-                 "share_of_gpu_time": dom["total_ms"] / total, "sum_kernel_ms_per_step": total})
+                 "share_of_gpu_time": dom["total_ms"] / total, "sum_kernel_ms_per_step": total,
+                 "by_function": {k: {"share": g["total_ms"] / total, "avg_us": g["total_ms"] * 1e3 / g["launches"], "launches": g["launches"],
+                                     "mfma_frac": g["flops"] / (g["total_ms"] * 1e9) / PEAK_BF16_TFLOPS if g["total_ms"] else 0.0}
+                                 for k, g in sorted(groups.items(), key=lambda kg: -kg[1]["total_ms"]) if g["flops"] > 0},
+                 "all_stroke_kernels": {"share_of_gpu_time": s_ms / total, "mfma_tflops": s_fl / (s_ms * 1e9) if s_ms else 0.0,
+                                        "mfma_frac": s_fl / (s_ms * 1e9) / PEAK_BF16_TFLOPS if s_ms else 0.0,
+                                        "hbm_gbs": s_by / (s_ms * 1e6) if s_ms else 0.0}})
     return roof, table
 
 
@@ -423,9 +454,10 @@ def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd", "csrc")
-    other = {"train.hip", "style.hip", "dhw_train_api.cpp", "dhw_style_api.cpp"}
+    sampler = {"convblock.hip", "enclayer.hip", "gemm.hip", "attn.hip", "misc.hip", "textside.hip", "enc_a_core.h", "attn_core.h", "gemm_core.h",
+               "epilogue.h", "heads_core.h", "dhw_common.h", "xcd_swizzle.h"}   # the kernels' translation units and the headers only they include
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")) and f not in other:
+        if f in sampler:
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -437,8 +469,7 @@ def pmc_traffic(label):
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC collection serialises kernels, so it is
     not repeated inside the timed run.  `stale` = the kernel sources changed since the passes were taken."""
     import glob
-    name = {"enc.fused_bc": "enc_bc_kernel", "enc.fused_bc+a": "enc_bc_kernel", "enc.fused_a": "enc_a_kernel",
-            "convblock.fused": "convblock_kernel"}.get(label)
+    name = KERNEL_FUNCTION.get(label, label if label in KERNEL_FUNCTION.values() else None)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
     if not name or not files:
         return None
@@ -455,25 +486,60 @@ def pmc_traffic(label):
         return None
 
 
-def fp32_mode(args, dev, text, style):
-    """The same workload through the fp32 parity mode (exact-f32 MFMA, the kernel set the goldens pin at 2e-5):
-    one warm-up + 2 timed steps."""
+def other_mode(args, dev, text, style, precision, num_layers):
+    """The same workload in another mode of the library — fp32_mode: the fp32 parity mode (exact-f32 MFMA, the kernel set the
+    goldens pin at 2e-5); nl4_mode: the class-default depth num_layers=4 in bf16.  One warm-up + 2 timed steps."""
     import torch
     import dhg_amd
     from dhg_amd import spec
     B, L, Lt, T = args.batch, args.L, args.Lt, args.T
-    m = dhg_amd.DiffusionModel(args.num_layers, precision="fp32", max_B=B, max_L=L, max_Lt=Lt).eval()
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(args.num_layers).items()})
+    m = dhg_amd.DiffusionModel(num_layers, precision=precision, max_B=B, max_L=L, max_Lt=Lt).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(num_layers).items()})
     dhg_amd.sample(m, text, style, L=L, T=T, seed=1)
     torch.cuda.synchronize(dev)
-    n = 2
+    n = 2 if precision == "fp32" else 5
     t0 = time.perf_counter()
     for k in range(n):
         dhg_amd.sample(m, text, style, L=L, T=T, seed=2 + k)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / n
+    fl, _ = m.work(L, Lt)
     del m
-    return {"value": B * L / dt, "unit": "stroke-points/s", "ms_per_step": dt * 1e3, "steps": n}
+    return {"value": B * L / dt, "unit": "stroke-points/s", "ms_per_step": dt * 1e3, "steps": n, "num_layers": num_layers, "precision": precision,
+            "model_tflops": fl * B * T / dt / 1e12}
+
+
+def train_step_figure(args, dev):
+    """BASELINE configs[4] on this GPU: a few updates of the native training step (forward + loss + backward + clip + Adam;
+    batch 32, L=480, Lt=50, fp32, hipGraph replay) — `python bench.py --train` is the full form of this measurement."""
+    import numpy as np
+    import torch
+    from dhg_amd import spec, train, train_model as tm
+    torch.set_num_threads(host_cores())
+    B, L, Lt = 32, 480, 50
+    sd = spec.synthetic_state_dict(args.num_layers, 128, 192, 256, seed=0)
+    model = tm.TrainModel(sd, num_layers=args.num_layers, device=dev, precision="fp32")
+    opt = train.Adam(model.parameters())
+    inp = spec.synthetic_inputs_range(0, B, L, Lt, seed=3, T=0)
+    g = torch.Generator().manual_seed(3)
+    strokes = torch.randn(B, L, 2, generator=g)
+    batch = {"strokes": torch.cat([strokes, (torch.rand(B, L, 1, generator=g) < 0.1).float()], dim=-1),
+             "text": torch.from_numpy(inp["text"]), "style": torch.from_numpy(inp["style"])}
+    alpha_set = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "sched.npz"))["alpha"])
+    step_fn = tm.GraphedTrainStep(model, opt, B, L, Lt)
+    losses = [float(step_fn(batch, alpha_set, k + 1)[0]) for k in range(3)]
+    torch.cuda.synchronize(dev)
+    n = 10
+    t0 = time.perf_counter()
+    for k in range(n):
+        step_fn(batch, alpha_set, 4 + k)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    gemm_tflops = model.last_gemm_flops / dt / 1e12
+    assert all(np.isfinite(losses)), "non-finite training loss"
+    return {"ms_per_update": dt * 1e3, "samples_per_s": B / dt, "batch": B, "L": L, "Lt": Lt, "dtype": "f32", "updates": n,
+            "launches_per_update": model.last_launches, "gemm_tflops": gemm_tflops, "gemm_roofline_frac": gemm_tflops / PEAK_F32_TFLOPS,
+            "peak_f32_mfma_tflops": PEAK_F32_TFLOPS, "workload": "configs[4] per-GPU shard: forward + diffusion loss + backward + clip + Adam, hipGraph replay"}
 
 
 def host_cores() -> int:

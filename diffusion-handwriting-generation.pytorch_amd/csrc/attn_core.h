@@ -194,6 +194,23 @@ DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, 
 //   * the units' phases are written unit-interleaved (all QK^T MFMAs, all maxima, all exponentials, all PV MFMAs): a wave
 //     that owns two heads overlaps one unit's MFMAs with the other's VALU work instead of running two serial chains.
 // The fp32 parity mode keeps attn_block_lds (exact reference operation order).
+// ---- V^T tiles in LDS (bf16 kernels): [channel][keys], keys PERMUTED inside every 32-key group so that the 8 k-values of a
+// PV operand fragment (keys 4g..4g+3 of the group's first 16-key tile and of its second, the order the P^T accumulators
+// supply) are 16 contiguous bytes: key 16 h + 4 g + r sits at position 8 g + 4 h + r.  One ds_read_b128 per fragment instead
+// of two ds_read_b64 — the LDS operand reads are what bounds the attention stages (profiles/r03_attention_ablation.log) and
+// 8-byte reads reach a fraction of the LDS rate at two waves per SIMD.  Global V^T buffers keep the plain key order; the
+// staging copy scatters each 16-byte piece (8 consecutive keys = two quads of one half h) as two 8-byte stores.
+// Row pad: 32 bytes = conflict-free ds_read_b128 lane groups (gemm_core.h); 16 where LDS is short (one 2-way group).
+template <typename T> DHW_DEV void vt_store_piece(char* row, int part, const uint4& v) {
+  if constexpr (sizeof(T) == 2) {
+    char* q = row + (part >> 2) * 64 + (part & 1) * 32 + ((part >> 1) & 1) * 8;   // group, g0 = 2 (part & 1), h = (part >> 1) & 1
+    *reinterpret_cast<uint2*>(q) = make_uint2(v.x, v.y);
+    *reinterpret_cast<uint2*>(q + 16) = make_uint2(v.z, v.w);
+  } else {
+    *reinterpret_cast<uint4*>(row + part * 16) = v;   // fp32 parity mode: plain order (attn_block_lds reads two halves)
+  }
+}
+
 #ifndef DHW_ATT_ABL
 #define DHW_ATT_ABL 0   // diagnostic builds only: bit0 = no MFMAs, bit1 = no exponentials, bit2 = no LDS operand reads, bit3 = no max / rescale
 #endif
@@ -277,15 +294,14 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int pp = 0; pp < NPF; ++pp) {
-        const T* vp = reinterpret_cast<const T*>(vt[u] + (16 * t) * SV) + 32 * pp;
-        const Frag<T> vf = (DHW_ATT_ABL & 4) ? pf[u][pp] : frag_load_halves(vp, vp + 16);
+        const Frag<T> vf = (DHW_ATT_ABL & 4) ? pf[u][pp] : frag_load(reinterpret_cast<const T*>(vt[u] + (16 * t) * SV + pp * 64 + g * 16));
         if constexpr (DHW_ATT_ABL & 1) { asm volatile("" ::"v"(vf.v)); o[u][t][pp] += (float)vf.v[0]; }
         else mma32(o[u][t], vf, pf[u][pp]);
       }
 }
 // One KB-key block for the UMAX (1 or 2) units of a wave: unit u = head hs + u * HS, active when that head exists (the
-// second unit of a wave may not).  kt0 / vt0: this lane's LDS addresses for head 0 (K tile row lane & 15; V^T tile row
-// lane & 15, key 4 (lane >> 4)); head h lies h * 64 channels further in both tiles.
+// second unit of a wave may not).  kt0 / vt0: this lane's LDS row addresses for head 0 (K tile row lane & 15; V^T tile row
+// lane & 15); head h lies h * 64 channels further in both tiles.
 template <typename T, int KB, bool MASKED, int UMAX>
 DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, const char* vt0, int SV, int hs, int HS, int H, int kb,
                         unsigned padbits, int Lk, float (&mr)[UMAX], float (&lr)[UMAX], f32x4 (&o)[UMAX][4]) {
@@ -308,7 +324,7 @@ DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, c
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
-      if (h < H) attn_block_lds<T, 64, KB>(qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
+      if (h < H) attn_block_lds<T, 64, KB>(qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV + 4 * ((threadIdx.x & 63) >> 4) * ES, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
     }
   }
 }
@@ -358,8 +374,26 @@ DHW_DEV void attn_stage_kv(char* kt, int SK, char* vt, int SV, const T* ksrc, in
       [&](int id) { const int r = id / cpr, cc = id - r * cpr;
                     return kb + r < kmax ? reinterpret_cast<const uint4*>(ksrc + (size_t)(kb + r) * ldk + cc * EPV) : nullptr; },
       [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(kt + r * SK + cc * 16); });
-  staged_copy<6>(C * PPR, tid, nthreads,
-      [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
-                    return kb + (part + 1) * EPV <= lpad ? reinterpret_cast<const uint4*>(vsrc + (size_t)ch * lpad + kb + part * EPV) : nullptr; },
-      [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(vt + ch * SV + part * 16); });
+  {
+    constexpr int U = 6;
+    const int total = C * PPR;
+    for (int base = tid; base < total; base += nthreads * U) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int id = min(base + u * nthreads, total - 1);
+        const int ch = id / PPR, part = id - ch * PPR;
+        v[u] = *reinterpret_cast<const uint4*>(vsrc + (size_t)ch * lpad + (kb + (part + 1) * EPV <= lpad ? kb + part * EPV : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int id = base + u * nthreads;
+        if (id < total) {
+          const int ch = id / PPR, part = id - ch * PPR;
+          const bool k = kb + (part + 1) * EPV <= lpad;
+          vt_store_piece<T>(vt + ch * SV, part, make_uint4(k ? v[u].x : 0u, k ? v[u].y : 0u, k ? v[u].z : 0u, k ? v[u].w : 0u));
+        }
+      }
+    }
+  }
 }

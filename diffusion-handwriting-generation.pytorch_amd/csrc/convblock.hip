@@ -28,7 +28,7 @@ namespace {
 #define CB_SILU_TILES(NT_, MT_, v) do { if constexpr (!(DHW_ABL & 8)) silu_tiles2<T, NT_, MT_>(v); } while (0)
 #define CB_BARRIER() do { if constexpr (!(DHW_ABL & 64)) lds_barrier(); } while (0)
 
-#define STAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0, (threadIdx.x >> 6) * 16 + slot, __builtin_amdgcn_s_memrealtime())
+#define STAMP(slot) DHW_STAMP_IF(p.stamps && (int)blockIdx.x == p.stagger && (threadIdx.x & 63) == 0, (threadIdx.x >> 6) * 16 + slot, __builtin_amdgcn_s_memrealtime())
 
 // Row stride of the h2 / output staging tile: the conflict-free operand padding, except for the 126-row tiles, where the
 // decoder block with the fused input stage would overflow LDS by 2 KB (128 channels with the 16-byte padding: one

@@ -149,6 +149,18 @@ struct CopyRegs {
       v[u] = *src(id < total ? id : total - 1);
     }
   }
+  // sink(id, value): the caller places the (already zero-selected) piece itself
+  template <typename SinkF, typename KeepF>
+  DHW_DEV void store_to(int total, int tid, int nthreads, SinkF sink, KeepF keep) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = tid + u * nthreads;
+      if (id < total) {
+        const bool k = keep(id);
+        sink(id, make_uint4(k ? v[u].x : 0u, k ? v[u].y : 0u, k ? v[u].z : 0u, k ? v[u].w : 0u));
+      }
+    }
+  }
   template <typename DstF, typename KeepF>
   DHW_DEV void store(int total, int tid, int nthreads, DstF dst, KeepF keep) {
 #pragma unroll

@@ -72,7 +72,7 @@ struct EncALds {
   char* VS;
 };
 template <typename T, int DM, int BM>
-constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + 16); }
+constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + OPAD<T>); }   // (V^T row pad: attn_core.h)
 
 // enc_a for the BM-row tile [m0, m0+BM) of sample b, of which the first rows_valid rows are this workgroup's to write.
 // p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
@@ -109,7 +109,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   // x tile, first block of text keys and of text values (usually all of them): every load is requested before the first
   // LDS store, so the three tiles cost one memory round trip together; its latency hides behind nothing (the q1 GEMM
   // needs x), the K / V tiles are only needed after q1.
-  constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + 16;
+  constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + OPAD<T>;
   constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBC / EPV;
   constexpr int UX = (BM * CPR + 511) / 512, UK = (KBC * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
   char* KT = m.KT;
@@ -133,8 +133,8 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
                [&](int id) { return m0 + id / CPR < p.Lk; });
     ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); },
              [&](int id) { return id / CPR < p.Lt; });
-    cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SVC + part * 16); },
-             [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
+    cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
+                [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
   }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
   PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
@@ -194,7 +194,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
         attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
       }
-      attn_units<T, KBC, true, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV + 4 * g * ES, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
+      attn_units<T, KBC, true, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
       if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
                                              // barrier behind the a1 store below does)
     }

@@ -46,15 +46,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // profiles/r03_head_enclayer_stage_stamps.log, d = 192: staged 2.7 / 2.0 us, computed 3.3 / 3.3 us.)
 // fp32 parity mode: single-buffered 32-key blocks (its tiles are twice as wide).
 template <typename T, int DM, int BM>
-constexpr size_t self_att_bytes(int kbs, int nbuf) { return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + 16)); }
+constexpr size_t self_att_bytes(int kbs, int nbuf, int vpad = 16) { return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + vpad)); }
 template <typename T, int DM, int BM>
 constexpr int self_kbs() { return sizeof(T) == 2 ? 64 : 32; }
 template <typename T, int DM, int BM>
 constexpr bool self_db() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, 2) <= 160 * 1024; }
+// V^T row pad: the conflict-free 32 bytes when the staging buffers still fit, else 16 (attn_core.h)
+template <typename T, int DM, int BM>
+constexpr int self_vpad() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, self_db<T, DM, BM>() ? 2 : 1, 32) <= 160 * 1024 ? 32 : 16; }
 template <typename T, int DM, int BM>
 constexpr size_t lds_bc_bytes() {
   constexpr size_t S = tile_stride<T>(DM);
-  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = self_att_bytes<T, DM, BM>(self_kbs<T, DM, BM>(), self_db<T, DM, BM>() ? 2 : 1);
+  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = self_att_bytes<T, DM, BM>(self_kbs<T, DM, BM>(), self_db<T, DM, BM>() ? 2 : 1, self_vpad<T, DM, BM>());
   return stages > att ? stages : att;
 }
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
     constexpr bool DB = self_db<T, DM, BM>();
-    constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + 16;
+    constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + self_vpad<T, DM, BM>();
     constexpr int BUFB = KBS * SK + DM * SV;   // one staged block: K tile, then V^T tile
     const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto commit = [&](int kb, char* KT, char* VT) {
       ck.store(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SK + cc * 16); },
                [&](int id) { return kb + id / CPR < p.Lk; });
-      cv.store(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR; return reinterpret_cast<uint4*>(VT + ch * SV + part * 16); },
-               [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
+      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SV, part, v); },
+                  [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
     };
     Frag<T> qf[UMAX][2];
     float mr[UMAX], lr[UMAX];
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       char* KN = R2 + (DB && !(ib & 1) ? BUFB : 0);   // where the next block goes
       if (DB && more) request(kb + KBS);
       if (ib < 3) STAMP(26 + 2 * ib);
-      attn_units<T, KBS, false, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV + 4 * g * ES, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
+      attn_units<T, KBS, false, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
       if (ib < 3) STAMP(27 + 2 * ib);
       if (more) {
         if (!DB) {          // single buffer: every wave must be past its reads before the tiles are rewritten

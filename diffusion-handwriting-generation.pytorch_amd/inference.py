@@ -40,7 +40,9 @@ def sample(model: DiffusionModel, text: torch.Tensor, style_vector: torch.Tensor
         L = stroke_length(Lt)
     if L % 8:
         raise ValueError("L must be a multiple of 8")
-    check_token_ids(text)
+    if not hasattr(model, "_validated_text"):
+        model._validated_text = []
+    check_token_ids(text, model._validated_text)   # (once per prompt tensor: the check is a host read)
     dev = model._device(text, style_vector)
     h = model._ensure_handle(dev, B, L, Lt, style_vector.shape[1])
     ret_dev = text.device

@@ -27,11 +27,22 @@ class _Node(nn.Module):
 VOCAB = 73   # nn.Embedding(73, d_model), reference text_style.py:71
 
 
-def check_token_ids(text: torch.Tensor) -> None:
+def check_token_ids(text: torch.Tensor, seen: list | None = None) -> None:
     """The reference's ``nn.Embedding`` raises IndexError for an id outside [0, 73); the kernels would clamp it.  One
-    reduction + one host read per call, in front of the launch."""
+    reduction + one host read — a blocking device sync when ``text`` lives on the GPU, so a caller that samples the same
+    prompt tensor repeatedly passes ``seen`` (a small list it owns): a tensor object that was validated before and has not
+    been written since (same object, same ``_version``) is not read again, and the next sampling call's launch does not wait
+    for the previous one to drain.  The list holds the validated tensors themselves, so their storage cannot be recycled
+    under a stale entry."""
+    if seen is not None:
+        for t, ver in seen:
+            if t is text and ver == text._version:
+                return
     if text.numel() and bool(((text < 0) | (text >= VOCAB)).any()):
         raise IndexError(f"index out of range in self: token ids must lie in [0, {VOCAB})")
+    if seen is not None:
+        seen.append((text, text._version))
+        del seen[:-4]
 
 
 def _torch_dtype_code(t: torch.Tensor) -> int:

@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     p.film = (float*)dev_rand(1 << 20, true); p.film_bs = 0; p.film_tot = 9280; p.f1 = 0; p.f2 = 256; p.f3 = 512;
     if (c.up) { p.up_h = dev_rand(rows * c.up * 2); p.up_cin = c.up; p.up_w = dev_rand((size_t)6 * c.up * c.cin); p.up_b = p.b_c1; p.up_low = p.x; }
     p.out = dev_rand(rows * c.cout * 2); p.out_f32 = 0; p.pool = nullptr; p.stamps = stamps;
+    p.stagger = getenv("STAMP_WG") ? atoi(getenv("STAMP_WG")) : 0;   // (stamped builds reuse the field: which workgroup writes the stamps)
     CK(hipMemset(stamps, 0, 256 * 8));
     for (int i = 0; i < 3; ++i) CK(launch_convblock(PREC_BF16, p, st));
     CK(hipStreamSynchronize(st));
