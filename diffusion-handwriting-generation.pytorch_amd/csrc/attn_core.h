@@ -214,9 +214,13 @@ template <typename T> DHW_DEV void vt_store_piece(char* row, int part, const uin
 #ifndef DHW_ATT_ABL
 #define DHW_ATT_ABL 0   // diagnostic builds only: bit0 = no MFMAs, bit1 = no exponentials, bit2 = no LDS operand reads, bit3 = no max / rescale
 #endif
-template <int D, int KB, bool MASKED, int NU>
+template <int D, int KB, bool MASKED, int NU, bool TAIL>
 DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char* const (&kt)[NU], int SK, const char* const (&vt)[NU], int SV, int kb,
                              unsigned padbits, int Lk, float (&m_run)[NU], float (&l_run)[NU], f32x4 (*o)[D / 16]) {
+  // No implicit fma contraction in here: with nothing between them (TAIL = false) hipcc fused `u = s * c` and `u - m` into
+  // fma(s, c, -m) — the non-robust form described above (NaN in the long-schedule stress test) — while the TAIL = true copy,
+  // where a select separates the two, kept them apart: two instantiations of one function with different results.
+#pragma clang fp contract(off)
   typedef bf16_t T;
   constexpr int DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
   static_assert(D % 32 == 0, "head width");
@@ -240,7 +244,8 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
   for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) s[u][t] = s[u][t] * c;
-  if (kb + KB > Lk) {   // (wave-uniform) the block that holds the end of the sequence
+  if constexpr (TAIL) {   // the block that holds the end of the sequence (the caller tests kb + KB > Lk: written as a run-time
+                          // test here, hipcc if-converted it into a compare + v_cndmask per score in EVERY block)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -257,6 +262,17 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[u][t][r] += ((padbits >> (4 * t + r)) & 1u) ? neg : 0.f;
   }
+  // the PV operand fragments are requested HERE, in front of the softmax arithmetic: their LDS latency (and the queueing
+  // behind the other waves' reads: the LDS operand reads bound this stage) then runs under the max / exp work
+  Frag<T> vf[NU][DT][NPF];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int pp = 0; pp < NPF; ++pp)
+        vf[u][t][pp] = (DHW_ATT_ABL & 4) ? qf[u][0] : frag_load(reinterpret_cast<const T*>(vt[u] + (16 * t) * SV + pp * 64 + g * 16));
+  __builtin_amdgcn_sched_barrier(0);
   float m_new[NU], alpha[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -270,6 +286,7 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
   Frag<T> pf[NU][NPF];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
+    const f32x4 negm = (f32x4){-m_new[u], -m_new[u], -m_new[u], -m_new[u]};   // (v_pk_add_f32)
     f32x4 psum = (f32x4){0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
@@ -294,9 +311,8 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int pp = 0; pp < NPF; ++pp) {
-        const Frag<T> vf = (DHW_ATT_ABL & 4) ? pf[u][pp] : frag_load(reinterpret_cast<const T*>(vt[u] + (16 * t) * SV + pp * 64 + g * 16));
-        if constexpr (DHW_ATT_ABL & 1) { asm volatile("" ::"v"(vf.v)); o[u][t][pp] += (float)vf.v[0]; }
-        else mma32(o[u][t], vf, pf[u][pp]);
+        if constexpr (DHW_ATT_ABL & 1) { asm volatile("" ::"v"(vf[u][t][pp].v)); o[u][t][pp] += (float)vf[u][t][pp].v[0]; }
+        else mma32(o[u][t], vf[u][t][pp], pf[u][pp]);
       }
 }
 // One KB-key block for the UMAX (1 or 2) units of a wave: unit u = head hs + u * HS, active when that head exists (the
@@ -316,7 +332,8 @@ DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, c
         const char* const kt[1] = {kt0 + h * 64 * ES};
         const char* const vt[1] = {vt0 + h * 64 * SV};
         float m1[1] = {mr[u]}, l1[1] = {lr[u]};
-        attn_block_bf16<64, KB, MASKED, 1>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        if (kb + KB > Lk) attn_block_bf16<64, KB, MASKED, 1, true>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        else attn_block_bf16<64, KB, MASKED, 1, false>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
         mr[u] = m1[0]; lr[u] = l1[0];
       }
     }
