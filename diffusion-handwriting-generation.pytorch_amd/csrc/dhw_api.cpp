@@ -206,6 +206,10 @@ struct dhw_handle {
   // graph cache for dhw_sample: the graph only touches library-owned staging buffers, so it is keyed by the
   // problem shape alone and replays for any caller pointers
   bool use_graph = true;
+  // teacher forcing of dhw_sample (dhw_debug_set_teacher): every `teach_every` steps x is captured and replaced
+  int teach_every = 0;
+  const float* teach_reset = nullptr;
+  float* teach_capture = nullptr;
   bool fuse_heads = true;       // dec1 evaluates heads + scheduler step (env DHW_FUSE_HEADS=0 -> separate launch)
   bool plane = true;            // all-steps text plane in dhw_sample (env DHW_PLANE=0 -> text side inside every step)
   bool fuse_up = true;          // decoder ConvBlocks evaluate Upsample + skip_conv while staging (env DHW_FUSE_UP=0 -> separate GEMM)
@@ -1362,6 +1366,13 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
   text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
   const int TC = plane_chunk(T);
   for (int step = 0, i = T - 1; i >= 0; --i, ++step) {
+    if (h->teach_every > 0 && step > 0 && step % h->teach_every == 0) {
+      // teacher forcing (tests only): x after `step` steps -> capture[k], x := reset[k]
+      const size_t k = (size_t)(step / h->teach_every - 1), off = (k * B + b0) * (size_t)L * 2;
+      hipError_t e = hipMemcpyAsync(h->teach_capture + off, w->d_xt, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(w->d_xt, h->teach_reset + off, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "teacher copy: %s", hipGetErrorString(e));
+    }
     if (h->plane && step % TC == 0) {
       // The text side (TextStyleEncoder + every layer's text K/V, text_style.py:91-104, model.py:38-42) depends on
       // (text, style, sigma_i) only and the sigma schedule is known: evaluate it for the next `ns` steps in ONE
@@ -1505,7 +1516,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
     nz = h->d_noise_stage;
   }
 
-  const bool graph = h->use_graph && !h->prof;
+  const bool graph = h->use_graph && !h->prof && !h->teach_every;
   if (!graph) {
     // eager launches: sub-batches still fork onto the side streams (concurrent kernels of different sub-batches);
     // profiling keeps one stream so the per-launch events bracket one kernel each
@@ -1656,6 +1667,15 @@ int dhw_set_streams(dhw_handle* h, int n) {
 int dhw_set_graph(dhw_handle* h, int on) {
   if (!h) return DHW_ERR_ARG;
   h->use_graph = on != 0;
+  return 0;
+}
+
+int dhw_debug_set_teacher(dhw_handle* h, const float* reset_dev, float* capture_dev, int every) {
+  if (!h) return DHW_ERR_ARG;
+  if (every < 0 || (every > 0 && (!reset_dev || !capture_dev))) return fail(h, DHW_ERR_ARG, "dhw_debug_set_teacher: bad arguments");
+  h->teach_every = every;
+  h->teach_reset = every ? reset_dev : nullptr;
+  h->teach_capture = every ? capture_dev : nullptr;
   return 0;
 }
 

@@ -45,6 +45,7 @@ def sample(model: DiffusionModel, text: torch.Tensor, style_vector: torch.Tensor
     check_token_ids(text, model._validated_text)   # (once per prompt tensor: the check is a host read)
     dev = model._device(text, style_vector)
     h = model._ensure_handle(dev, B, L, Lt, style_vector.shape[1])
+    model._apply_teacher()
     ret_dev = text.device
     with torch.cuda.device(dev):
         t = text.to(dev, torch.int64).contiguous()

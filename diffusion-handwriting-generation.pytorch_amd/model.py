@@ -188,6 +188,25 @@ class DiffusionModel(nn.Module):
         _lib.check(_lib.lib().dhw_debug_randn(h, seed, first_sample, B, L, it, buf.ctypes.data_as(C.POINTER(C.c_float))), h)
         return torch.from_numpy(buf)
 
+    def set_teacher(self, reset: "torch.Tensor | None", every: int = 0) -> "torch.Tensor | None":
+        """Teacher forcing of the next sample() calls (include/dhw_debug.h, tests only): `reset` [K,B,L,2] on the model's
+        device; returns the capture tensor [K,B,L,2] the library fills (x after k*every steps), or None when switched off.
+        Takes effect when the next sample() call has its handle (handles are created lazily, per problem size)."""
+        if reset is None or every <= 0:
+            self._teacher = (None, None, 0)
+            return None
+        reset = reset.to(torch.float32).contiguous()
+        cap = torch.empty_like(reset)
+        self._teacher = (reset, cap, every)   # (keeps the buffers alive)
+        return cap
+
+    def _apply_teacher(self):
+        t = getattr(self, "_teacher", None)
+        if t is not None:
+            reset, cap, every = t
+            _lib.check(_lib.lib().dhw_debug_set_teacher(self._handle, reset.data_ptr() if every else None, cap.data_ptr() if every else None, every),
+                       self._handle)
+
     def profile(self, on: bool):
         _lib.check(_lib.lib().dhw_profile_enable(self._handle, int(on)), self._handle)
         if on:

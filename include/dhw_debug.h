@@ -33,6 +33,13 @@ int dhw_set_streams(dhw_handle*, int n);
 /* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
 int dhw_set_graph(dhw_handle*, int on);
 
+/* Teacher forcing of dhw_sample, for long-schedule parity tests (the random-init reverse process grows by 1/sqrt(1 - beta)
+ * per step, so a free-running T = 1000 trajectory leaves every meaningful range; SURVEY 7 "hard parts"): with every > 0 the
+ * next dhw_sample calls run eagerly and, in front of step k*every (k = 1, 2, ... while k*every < T), copy the state x
+ * [B,L,2] reached so far to capture_dev[k-1] and continue from reset_dev[k-1] (device buffers of (T-1)/every x [B,L,2] floats,
+ * owned by the caller, alive until the calls have completed).  every = 0 switches it off. */
+int dhw_debug_set_teacher(dhw_handle*, const float* reset_dev, float* capture_dev, int every);
+
 /* The device noise generator on its own: the N(0,1) draws of `B` samples x `L` positions x 2 for sampler iteration
  * `iter` (-1 = x_T, k >= 0 = the draw step k adds) under (seed, first_sample), copied to host_dst [B,L,2].
  * Exactly the values dhw_sample(noise = NULL) consumes.  Synchronises the device. */

@@ -223,13 +223,17 @@ def forward(sd, strokes, text, sigma, style_vector, taps=None):
 
 
 def sample(sd, text, style_vector, L: int, noise, T: int = 60, mode: str = "new",
-           snapshots=(), grad: bool = False):
+           snapshots=(), grad: bool = False, teacher=None):
     """inference.py:80-96 with the RNG draws replaced by ``noise``.
 
     noise: f32 [T+1, B, L, 2]; noise[0] = x_T, noise[1 + (T-1-i)] = z drawn at
     loop index i (i = T-1 ... 0), i.e. in consumption order.  In 'standard'
     mode the i == 0 draw is unused (add_sigma = bool(i), inference.py:92).
     Returns (out [B,L,3], {k: x after k steps}).
+
+    teacher = (every, reset [K,B,L,2]): teacher forcing for long schedules — in front of step k*every (k >= 1) the
+    state reached so far is recorded (snaps[k*every]) and replaced by reset[k-1]; the reverse process of a random-init
+    model gains 1/sqrt(1-beta) per step, so a free-running T=1000 trajectory leaves every meaningful range.
     """
     beta_set = get_beta_set(T)
     alpha_set = get_alpha_set(beta_set)
@@ -240,6 +244,9 @@ def sample(sd, text, style_vector, L: int, noise, T: int = 60, mode: str = "new"
     ctx = torch.enable_grad() if grad else torch.no_grad()
     with ctx:
         for step, i in enumerate(range(T - 1, -1, -1)):
+            if teacher is not None and step > 0 and step % teacher[0] == 0:
+                snaps[step] = x.detach().clone()
+                x = teacher[1][step // teacher[0] - 1].clone()
             alpha = alpha_set[i] * torch.ones((bs, 1, 1))
             beta = beta_set[i] * torch.ones((bs, 1, 1))
             a_next = alpha_set[i - 1] if i > 1 else torch.tensor(1.0)  # inference.py:87
@@ -253,6 +260,24 @@ def sample(sd, text, style_vector, L: int, noise, T: int = 60, mode: str = "new"
                 snaps[step + 1] = x.detach().clone()
     out = torch.cat((x, pen.unsqueeze(2)), dim=2)  # inference.py:96
     return out.detach(), snaps
+
+
+# --------------------------------------------------------------------------
+# training loss (loss.py:29-37) and the perturbation of train.py:41-44
+# --------------------------------------------------------------------------
+def loss_fn(eps, score_pred, pen_lifts, pen_lifts_pred, alphas):
+    """loss.py:29-37: score_loss = mean(sum((eps - score)^2, -1)); pen loss = mean(mean_L(BCE(pred, clamp(pen))) * abar).
+    eps, score_pred [B,L,2]; pen_lifts, pen_lifts_pred [B,L]; alphas [B,1].  Returns (total, score_loss, pen_loss)."""
+    score_loss = ((eps - score_pred) ** 2).sum(dim=-1).mean()
+    pen = torch.clamp(pen_lifts, min=1e-7, max=1 - 1e-7)
+    pen_loss = (F.binary_cross_entropy(pen_lifts_pred, pen, reduction="none").mean(dim=1) * alphas.squeeze(-1)).mean()
+    return score_loss + pen_loss, score_loss, pen_loss
+
+
+def perturb(strokes, eps, alphas):
+    """train.py:41-44: x_t = sqrt(abar) * x_0 + sqrt(1 - abar) * eps with abar [B,1] broadcast over [B,L,2]."""
+    a = alphas.reshape(-1, 1, 1)
+    return torch.sqrt(a) * strokes + torch.sqrt(1 - a) * eps
 
 
 # --------------------------------------------------------------------------

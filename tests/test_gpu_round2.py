@@ -148,27 +148,43 @@ def test_config3_long_schedule_full_size_properties():
 
 
 def test_config3_long_schedule_matches_the_oracle(golden_dir):
-    """One configs[3] prompt (L=1000, Lt=62, T=1000) against the oracle's output for the same seeds
-    (tests/golden/config3_oracle.npz, written by oracle/make_config3_fixture.py: the oracle needs ~4 min for this case).
-    The trajectory ends at |x| ~ 1e15 (the schedule's own gain), so stroke errors are relative to max|x|, and the pen
-    probabilities are saturated at exactly 0 / 1, so they are compared as bits.  fp32: measured 5e-6 relative, identical
-    pen bits.  bf16: measured 0.95 % relative; a saturated pen bit flips where the huge logit's sign hangs on a
-    cancellation (fraction reported, < 5 % required)."""
+    """BASELINE configs[3] (L=1000, Lt=62, T=1000) against the oracle, TEACHER FORCED (round 3; SURVEY 7 "hard parts"): the
+    reverse process of a random-init model gains 1/sqrt(1-beta) per step (1e15 over this schedule), so the state is
+    captured and reset to a seeded N(0,1) draw every 16 steps — in the oracle (ref_cpu.sample(teacher=...), fixture
+    tests/golden/config3_oracle.npz written by oracle/make_config3_fixture.py) and in the library
+    (dhw_debug_set_teacher).  |x| stays O(10), so the tolerances mean something, while all 1000 schedule indices, FiLM rows
+    and the 16 text-plane chunks are exercised on two prompts with the plain synthetic weights:
+    fp32 — every captured state and the final strokes within 1e-4 of max|x|, pen bits identical;
+    bf16 — within 2 % of max|x|, pen bits may differ only where the oracle's probability is within 0.02 of 0.5."""
     g = np.load(os.path.join(golden_dir, "config3_oracle.npz"))
-    B, L, Lt, T = int(g["B"]), int(g["L"]), int(g["Lt"]), int(g["T"])
-    assert (B, L, Lt, T) == (1, 1000, 62, 1000) and float(g["out_scale"]) == OUT_SCALE
-    ref = torch.from_numpy(g["out"])
-    sd = _sd(out_scale=OUT_SCALE)
+    B, L, Lt, T, every = (int(g[k]) for k in ("B", "L", "Lt", "T", "every"))
+    assert (B, L, Lt, T, every) == (2, 1000, 62, 1000, 16)
+    rs = int(g["row_stride"])
+    ref_out, ref_cap = torch.from_numpy(g["out"]), torch.from_numpy(g["captures"])
+    resets = torch.randn((T - 1) // every, B, L, 2, generator=torch.Generator().manual_seed(int(g["reset_seed"])))
     inp = spec.synthetic_inputs(B, L, Lt, seed=int(g["seed"]), T=T)
     tx, sv, nz = (torch.from_numpy(inp[k]) for k in ("text", "style", "noise"))
-    scale = ref[..., :2].abs().max().item()
+    scale = max(ref_out[..., :2].abs().max().item(), ref_cap.abs().max().item())
+    assert scale < 1e3, scale          # the forced trajectory stays in a meaningful range
     rep = {"max_abs_x": scale}
-    for prec, tol_x, tol_bits in (("fp32", 1e-4, 0.0), ("bf16", 0.03, 0.05)):
-        m = _model(prec, B, L, Lt, sd)
+    for prec, tol_x in (("fp32", 1e-4), ("bf16", 0.02)):
+        m = _model(prec, B, L, Lt)
+        cap = m.set_teacher(resets.cuda(), every)
         out = dhg_amd.sample(m, tx.cuda(), sv.cuda(), L=L, T=T, noise=nz.cuda()).cpu()
-        ex = (out[..., :2] - ref[..., :2]).abs().max().item() / scale
-        bits = (out[..., 2].round() != ref[..., 2].round()).float().mean().item()
-        rep[prec] = {"rel_err_x": ex, "pen_bit_mismatch_frac": bits}
-        print("configs[3] vs oracle:", json.dumps(rep))
-        assert torch.isfinite(out).all() and ex < tol_x and bits <= tol_bits, rep
+        cap = cap.cpu()[:, :, ::rs]
+        m.set_teacher(None)
+        e_cap = (cap - ref_cap).abs().amax(dim=(1, 2, 3)) / scale            # per 16-step segment
+        e_out = (out[..., :2] - ref_out[..., :2]).abs().max().item() / scale
+        flipped = out[..., 2].round() != ref_out[..., 2].round()
+        dist = (ref_out[..., 2][flipped] - 0.5).abs()
+        rep[prec] = {"rel_err_segments_max": e_cap.max().item(), "rel_err_final": e_out, "pen_bits_flipped": int(flipped.sum()),
+                     "max_dist_to_half_of_flips": dist.max().item() if flipped.any() else 0.0,
+                     "max_abs_dp": (out[..., 2] - ref_out[..., 2]).abs().max().item()}
+        print("configs[3] teacher-forced vs oracle:", json.dumps(rep))
+        assert torch.isfinite(out).all() and torch.isfinite(cap).all()
+        assert e_cap.max().item() < tol_x and e_out < tol_x, rep
+        if prec == "fp32":
+            assert not flipped.any(), rep
+        else:
+            assert (dist < 0.02).all() and flipped.float().mean().item() < 0.01, rep
         del m

@@ -180,6 +180,65 @@ def test_whole_model_gradients_match_the_reference_autograd(golden_dir, fixture)
             _close(model.p[k[2:]].g, torch.from_numpy(f[k]), 1e-3)
 
 
+def test_gradients_at_the_benchmarked_shape_match_the_oracle_autograd():
+    """BASELINE configs[4] at the shape `bench.py --train` runs (L=480, Lt=50, S=14; B=4 of the 32 per GPU so the oracle's
+    autograd pass fits the test budget): forward + loss + backward through the library against oracle/ref_cpu.forward +
+    the reference's loss (loss.py:29-37) under torch autograd on the CPU, same seeded weights / inputs / eps / abar / style
+    keep-mask.  The small fixtures (model_grad.npz: B=2, L=64, Lt=10) never reach the split-K weight-gradient path over
+    thousands of rows with its fp32 atomics, nor the multi-block attention of L/2 = 240 keys; this does.  Every one of the
+    323 parameter gradients: norm and projection on a fixed random direction, relative to the gradient's own norm
+    (floored at 1e-4 of the largest).  Tolerance 2e-4 (fp32 accumulation order over 1920-row contractions; measured 6.6e-6)."""
+    from oracle import ref_cpu
+    B, L, Lt, S = 4, 480, 50, 14
+    sd_np = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    inp = spec.synthetic_inputs(B, L, Lt, S=S, seed=21, pad=3)
+    g = torch.Generator().manual_seed(5)
+    eps = torch.randn(B, L, 2, generator=g)
+    pen = (torch.rand(B, L, generator=g) < 0.1).float()
+    alphas = torch.rand(B, 1, generator=g) * 0.9 + 0.05
+    keep = (torch.rand(B, S, 1280, generator=g) >= 0.3).float()
+    strokes, text, style = (torch.from_numpy(inp[k]) for k in ("strokes", "text", "style"))
+
+    # --- oracle: CPU restatement of the reference under autograd (Dropout(0.3) on the style input = keep / 0.7, text_style.py:83,92)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    x_pert = ref_cpu.perturb(strokes, eps, alphas)
+    score_ref, pen_ref = ref_cpu.forward(sd, x_pert, text, torch.sqrt(alphas), style * keep / 0.7)
+    loss_ref, sl_ref, pl_ref = ref_cpu.loss_fn(eps, score_ref, pen, pen_ref, alphas)
+    loss_ref.backward()
+
+    # --- library
+    model = tm.TrainModel(sd_np, num_layers=2, device=DEV, drop_rate=0.0)
+    xp = train.perturb(strokes, eps, alphas)
+    _close(xp, x_pert, 1e-6)
+    score, pen_pred = model.forward(xp, text, torch.sqrt(alphas), style, keep, None)
+    _close(score, score_ref, 1e-4)
+    _close(pen_pred, pen_ref, 1e-4)
+    out, d_score, d_pen = train.loss_fn(eps, score, pen, pen_pred, alphas)
+    assert np.allclose(out.cpu().numpy(), [loss_ref.item(), sl_ref.item(), pl_ref.item()], rtol=5e-5), (out, loss_ref)
+    model.backward(d_score, d_pen)
+    torch.cuda.synchronize()
+
+    names = list(model.names)
+    assert len(names) == 323
+    ref_norms = np.array([float(sd[n].grad.double().norm()) for n in names])
+    floor = 1e-4 * ref_norms.max()
+    worst = (0.0, "")
+    for i, n in enumerate(names):
+        gr = model.p[n].g
+        assert gr is not None, f"no gradient reached {n}"
+        gr = gr.cpu().double().numpy().ravel()
+        rf = sd[n].grad.double().numpy().ravel()
+        pr = probe(i, gr.size).astype(np.float64)
+        scale = max(ref_norms[i], floor)
+        e_norm = abs(np.linalg.norm(gr) - ref_norms[i]) / scale
+        e_dot = abs(np.dot(gr, pr) - np.dot(rf, pr)) / scale
+        e_max = np.abs(gr - rf).max() / scale
+        worst = max(worst, (max(e_norm, e_dot), n))
+        assert e_norm < 2e-4 and e_dot < 2e-4 and e_max < 5e-3, (n, e_norm, e_dot, e_max, ref_norms[i])
+    print("configs[4] shape: worst parameter-gradient error (relative to its norm):", worst)
+
+
 @pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_train_steps_follow_the_reference_trajectory(golden_dir, mode):
     """tests/golden/train_traj.npz: four updates of the reference's train_step (train.py:26-67) with its optimizer stack
@@ -291,7 +350,8 @@ def test_device_drawn_encoder_dropout_trains():
         return [float(step(batch, None, k, eps=eps, alphas=alphas, style_keep=keep)[0]) for k in indices]
     a = first_losses([1, 2, 1])
     b = first_losses([1])
-    assert a[0] == b[0] and abs(a[0] - a[1]) > 1e-4 and abs(a[0] - a[2]) < 1e-4, (a, b)
+    # (the loss sums are fp32 atomics over blocks: the same masks give the same loss up to summation order, not bit for bit)
+    assert abs(a[0] - b[0]) < 2e-6 * abs(a[0]) and abs(a[0] - a[1]) > 1e-4 and abs(a[0] - a[2]) < 1e-4, (a, b)
 
 
 def test_fit_trains_and_its_checkpoint_feeds_the_sampler(tmp_path):
