@@ -7,7 +7,7 @@ tag=${1:-rXX}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32"
+BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- $BENCH > "$out/trace.log" 2>&1
 echo "[profile_all] kernel trace done"
