@@ -14,7 +14,7 @@
 
 namespace {
 
-std::string g_terr;
+thread_local std::string g_terr;   // per calling thread, as dhw_train_last_error() is documented
 
 int tfail(int code, const char* fmt, ...) {
   char tmp[512];
@@ -118,19 +118,19 @@ int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* cons
                    float beta1, float beta2, float eps, float weight_decay, int step, float max_norm, float* grad_norm_out, void* hip_stream) {
   if (nbuf < 1 || !p || !g || !m || !v || !n || step < 1) return tfail(DHW_ERR_ARG, "dhw_train_adam: bad argument");
   hipStream_t st = (hipStream_t)hip_stream;
+  // the squared-norm scalar: allocated once per calling thread and kept (a hipMalloc / hipFree pair and a stream
+  // synchronisation per update used to sit here; an error return between them leaked the allocation)
+  static thread_local float* sq_keep = nullptr;
   float* sq = nullptr;
   if (max_norm > 0.f || grad_norm_out) {
-    THIP(hipMalloc((void**)&sq, sizeof(float)));
+    if (!sq_keep) THIP(hipMalloc((void**)&sq_keep, sizeof(float)));
+    sq = sq_keep;
     THIP(hipMemsetAsync(sq, 0, sizeof(float), st));
     for (int i = 0; i < nbuf; ++i) THIP(launch_sqnorm(g[i], n[i], sq, st));
   }
   for (int i = 0; i < nbuf; ++i)
     THIP(launch_adam(p[i], g[i], m[i], v[i], n[i], lr, beta1, beta2, eps, weight_decay, step, max_norm > 0.f ? sq : nullptr, max_norm, st));
-  if (sq) {
-    if (grad_norm_out) THIP(hipMemcpyAsync(grad_norm_out, sq, sizeof(float), hipMemcpyDeviceToDevice, st));   // (squared norm)
-    THIP(hipStreamSynchronize(st));
-    THIP(hipFree(sq));
-  }
+  if (sq && grad_norm_out) THIP(hipMemcpyAsync(grad_norm_out, sq, sizeof(float), hipMemcpyDeviceToDevice, st));   // (squared norm; stream-ordered)
   return 0;
 }
 

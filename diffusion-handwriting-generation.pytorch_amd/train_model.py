@@ -111,7 +111,7 @@ class Tape:
         if extent(a_off, sam, M, sak, Kt, za) >= A.numel() or extent(b_off, sbk, Kt, sbn, N, zb, sbt) >= Bm.numel() \
                 or extent(c_off, scm, M, scn, N, zc) >= Cm.numel() or min(a_off, b_off, c_off) < 0:
             raise ValueError("gemm operand extents exceed their buffers")
-        if max(A.numel(), Bm.numel()) >= 2 ** 31:
+        if max(A.numel(), Bm.numel(), Cm.numel()) >= 2 ** 31:
             raise ValueError("gemm operands are addressed with 32-bit element offsets")
         if (a_shift or a_tap_shift) and (lr < 1 or M % lr):
             raise ValueError("a row-shifted gemm needs whole samples of lr rows")
@@ -404,7 +404,10 @@ class TrainModel:
                     boff.append(self.offset[f"{base}.{kind}.bias"] + torch.arange(Cc, dtype=torch.int64))
                 col += 2 * Cc
         self.film_total = col
-        self.film_woff, self.film_boff = torch.cat(woff).to(self.dev), torch.cat(boff).to(self.dev)
+        woff_all = torch.cat(woff)
+        if bool((woff_all % 4 != 0).any()):   # film_table_fwd_kernel reads each 32-float weight row as f32x4 from flat + offset
+            raise ValueError("the FiLM weight rows are not 16-byte aligned in the flat parameter buffer (unexpected state_dict sizes / order)")
+        self.film_woff, self.film_boff = woff_all.to(self.dev), torch.cat(boff).to(self.dev)
         self.c1 = self.p["input_dense.weight"].d.shape[0]
         self._pe = {}
         self.tape = None
@@ -734,11 +737,16 @@ def read_train_config(config_path) -> dict:
             "seed": int((cfg.get("experiment") or {}).get("seed", 0))}
 
 
-def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, seed=0, log=print):
+def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, seed=0, log=print, precision="fp32"):
     """The reference's ``TrainingLoop.train`` (train.py:84-134): updates until ``training_args.steps``, a log line every
     ``log_freq`` updates (mean losses since the last line), ``checkpoint_<n>.pth`` every ``save_freq``, ``model_final.pth`` at
-    the end.  One process per GPU under ``torch.distributed.run`` (LOCAL_RANK picks the device, gradients averaged by RCCL);
-    rank 0 logs and saves.  Returns the trained ``TrainModel``."""
+    the end.  Cadence and numbering are the reference's own (train.py:111-126): after update number ``count`` it tests
+    ``(count + 1) % freq`` and labels the line / file ``count + 1`` — so ``checkpoint_1000.pth`` holds 999 updates, and runs line
+    up with the reference step for step.  One process per GPU under ``torch.distributed.run`` (LOCAL_RANK picks the device,
+    gradients averaged by RCCL); rank 0 logs and saves.  ``training_args.batch_size`` is the PER-RANK batch (the reference is
+    single-process, so its 96 is one GPU's batch): N ranks train on a global batch of N x batch_size — divide it in the config to
+    keep the reference's global batch.  ``precision``: "fp32" (the reference's) or "bf16" (bf16-rounded GEMM operands, fp32
+    accumulation and fp32 master weights / optimizer state).  Returns the trained ``TrainModel``."""
     import os
     import time
     from . import spec
@@ -757,7 +765,7 @@ def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, 
     if L % 8:
         raise ValueError("dataset_args.max_seq_len must be a multiple of 8 (configs/best.yml:12)")
     sd = read_state_dict(init) if init else spec.synthetic_state_dict(cfg["num_layers"], cfg["c1"], cfg["c2"], cfg["c3"], seed=seed)
-    model = TrainModel(sd, num_layers=cfg["num_layers"], device=dev, drop_rate=cfg["dropout"], seed=seed)
+    model = TrainModel(sd, num_layers=cfg["num_layers"], device=dev, drop_rate=cfg["dropout"], seed=seed, precision=precision)
     opt = Adam(model.parameters(), betas=cfg["betas"], weight_decay=cfg["weight_decay"], max_norm=cfg["clip_grad"] or 0.0)
     step_fn = GraphedTrainStep(model, opt, B, L, Lt, d_model=2 * cfg["c1"], warmup=cfg["warmup"], seed=seed)
     alpha_set = torch.cumprod(1 - (0.02 + torch.exp(torch.linspace(math.log(1e-5), math.log(0.4), 60))), dim=0)   # utils/nn.py:19-39
@@ -781,15 +789,15 @@ def fit(config_path, data_path=None, out_dir="runs/exp", steps=None, init=None, 
     acc, t0 = [], time.time()
     for count in range(1, n_steps + 1):
         acc.append(step_fn(next_batch(), alpha_set, count).clone())
-        if count % cfg["log_freq"] == 0:
+        if (count + 1) % cfg["log_freq"] == 0:      # (train.py:111: the reference's own off-by-one, reproduced)
             m = torch.stack(acc).mean(0).tolist()   # (one host sync per log line)
             acc = []
             if rank == 0:
-                log(f"Step {count} | Loss: {m[0]:.3f} | Score: {m[1]:.3f} | Pen: {m[2]:.3f} | Time: {time.time() - t0:.3f} sec")
-        if rank == 0 and count % cfg["save_freq"] == 0:
+                log(f"Step {count + 1} | Loss: {m[0]:.3f} | Score: {m[1]:.3f} | Pen: {m[2]:.3f} | Time: {time.time() - t0:.3f} sec")
+        if rank == 0 and (count + 1) % cfg["save_freq"] == 0:
             # save_checkpoint's form (checkpoint.py:244): {"meta", "state_dict"}; model_final.pth is the bare state_dict (train.py:131)
             torch.save({"meta": None, "state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
-                       os.path.join(out_dir, f"checkpoint_{count}.pth"))
+                       os.path.join(out_dir, f"checkpoint_{count + 1}.pth"))
     if rank == 0:
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "model_final.pth"))
     if world > 1:

@@ -11,7 +11,9 @@ mkdir -p tools/bin
 # their own stamped kernel objects
 S=tools/bin/stamped
 mkdir -p $S
-for f in convblock enclayer gemm; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_STAMPS -x hip -c $C/$f.hip -o $S/$f.o & done; wait
+pids=""
+for f in convblock enclayer gemm; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_STAMPS -x hip -c $C/$f.hip -o $S/$f.o & pids="$pids $!"; done
+for pid in $pids; do wait $pid; done   # (a bare `wait` hides a failed compile from `set -e`)
 P=$S
 $H -c tools/bench_conv.cpp -o tools/bin/bench_conv.o && hipcc --offload-arch=gfx950 tools/bin/bench_conv.o $P/convblock.o $P/enclayer.o -o tools/bin/bench_conv
 $H -c tools/bench_enc.cpp -o tools/bin/bench_enc.o && hipcc --offload-arch=gfx950 tools/bin/bench_enc.o $P/enclayer.o -o tools/bin/bench_enc

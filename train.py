@@ -9,8 +9,10 @@ is the reference's yml (training_args: steps, batch_size, warmup_steps, clip_gra
 log_freq, save_freq; dataset_args: max_seq_len, max_text_len; optimizer.params: betas, weight_decay).  `--data`: a torch file
 {"strokes" [N,L,3], "text" [N,Lt] int64, "style" [N,14,1280]} of preprocessed samples (the reference's IAMDataset items,
 dataset.py:143-157; read with weights_only=True); without it, synthetic batches of the configured shape (smoke / benchmark
-runs — the IAM corpus and its preprocessing are outside this package).  Writes checkpoint_<n>.pth / model_final.pth in the
-reference's on-disk form (a torch-saved state_dict with the reference's 323 keys)."""
+runs — the IAM corpus and its preprocessing are outside this package).  Writes checkpoint_<n>.pth in save_checkpoint's form
+({"meta": None, "state_dict": ...}, reference checkpoint.py:244) and model_final.pth as the bare state_dict (train.py:131),
+both with the reference's 323 keys; cadence and numbering follow the reference ((count + 1) % freq, see fit()).
+--precision bf16 selects the mixed-precision GEMMs (fp32 master weights and optimizer state); batch_size is per rank."""
 import argparse
 
 import dhg_amd
@@ -24,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, help="override training_args.steps")
     ap.add_argument("--init", help="state_dict to start from (.pth)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="GEMM operand precision (fp32 = the reference's)")
     a = ap.parse_args(argv)
     # the host side draws abar and assembles batches with small torch CPU ops: one thread per visible core on a box whose
     # cgroup grants fewer makes each of them take milliseconds
@@ -35,7 +38,7 @@ def main(argv=None):
     except (OSError, ValueError):
         cores = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(cores, 16)))
-    dhg_amd.train_model.fit(a.config, a.data, a.out, steps=a.steps, init=a.init, seed=a.seed)
+    dhg_amd.train_model.fit(a.config, a.data, a.out, steps=a.steps, init=a.init, seed=a.seed, precision=a.precision)
 
 
 if __name__ == "__main__":
