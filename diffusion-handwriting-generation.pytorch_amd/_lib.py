@@ -96,6 +96,10 @@ SIGNATURES = {
     "dhw_op_add_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "dhw_op_film": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, _P]),
     "dhw_op_film_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "dhw_op_film_act": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "dhw_op_film_act_bwd": (C.c_int, [_P, _P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "dhw_op_ln_film": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _LL, _P, _P, _P, _P]),
+    "dhw_op_ln_film_bwd": (C.c_int, [_P, _P, _P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "dhw_op_layernorm": (C.c_int, [_P, _LL, C.c_int, _P, _P, _P, _P]),
     "dhw_op_layernorm_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, _P, C.c_int, _P]),
     "dhw_op_softmax": (C.c_int, [_P, _LL, C.c_int, _LL, _P, C.c_float, _P, _P]),

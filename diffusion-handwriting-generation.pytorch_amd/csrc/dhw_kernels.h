@@ -242,6 +242,13 @@ hipError_t launch_add_rows(const float* x, const float* table, long n, long per_
 hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, float* y, hipStream_t st);
 hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, long pstride, int B, int L, int C, float* du, int accumulate, float* dgam,
                             float* dbet, hipStream_t st);
+hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* y, hipStream_t st);
+hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
+                               int accumulate, float* dgam, float* dbet, hipStream_t st);
+hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, float* y, float* mean, float* rstd,
+                              hipStream_t st);
+hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,
+                              float* dx, int accumulate, float* dgam, float* dbet, hipStream_t st);
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st);
 hipError_t launch_ln_bwd(const float* dy, const float* y, const float* rstd, long rows, int C, float* dx, int accumulate, hipStream_t st);
 hipError_t launch_softmax_fwd(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p, hipStream_t st);

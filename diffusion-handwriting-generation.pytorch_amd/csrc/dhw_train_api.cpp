@@ -304,6 +304,28 @@ int dhw_op_film_bwd(const float* dy, const float* x, const float* gamma, long lo
   THIP(launch_film_bwd2(dy, x, gamma, pstride, B, L, C, dx, accumulate, dgamma, dbeta, (hipStream_t)st));
   return 0;
 }
+int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* y, void* st) {
+  OPCHECK(x && gamma && beta && y && B > 0 && L > 0 && C > 0 && C % 4 == 0 && pstride % 4 == 0, "dhw_op_film_act");
+  THIP(launch_film_act_fwd(x, gamma, beta, pstride, B, L, C, act, y, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* dx,
+                        int accumulate, float* dgamma, float* dbeta, void* st) {
+  OPCHECK(dy && x && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0, "dhw_op_film_act_bwd");
+  THIP(launch_film_act_bwd(dy, x, gamma, beta, pstride, B, L, C, act, dx, accumulate, dgamma, dbeta, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, float* y, float* mean, float* rstd, void* st) {
+  OPCHECK(x && gamma && beta && y && mean && rstd && B > 0 && L > 0 && C > 0, "dhw_op_ln_film");
+  THIP(launch_ln_film_fwd(x, (long)B * L, C, gamma, beta, pstride, L, y, mean, rstd, (hipStream_t)st));
+  return 0;
+}
+int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,
+                       float* dx, int accumulate, float* dgamma, float* dbeta, void* st) {
+  OPCHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0 && C <= 512, "dhw_op_ln_film_bwd");
+  THIP(launch_ln_film_bwd(dy, x, mean, rstd, gamma, pstride, B, L, C, dx, accumulate, dgamma, dbeta, (hipStream_t)st));
+  return 0;
+}
 int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* st) {
   OPCHECK(x && y && mean && rstd && rows > 0 && C > 0, "dhw_op_layernorm");
   THIP(launch_ln_fwd(x, rows, C, y, mean, rstd, (hipStream_t)st));

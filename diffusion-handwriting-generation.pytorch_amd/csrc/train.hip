@@ -704,6 +704,122 @@ __global__ __launch_bounds__(256) void film_bwd2_kernel(const float* d, const fl
   }
 }
 
+// ---- fused element-wise chains (round 3): the element-wise launches of the op-by-op tape are HBM-bound passes over
+// [rows, C] fp32 activations (5-10 us each, ~25 % of an update); FiLM -> SiLU and LayerNorm -> FiLM are evaluated in ONE pass
+// each way, the intermediate (FiLM output / normalised rows) is recomputed in the backward instead of stored and re-read.
+// y = act ? SiLU(x gamma[b] + beta[b]) : x gamma[b] + beta[b];   4 channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void film_act_fwd_kernel(const float* x, const float* gam, const float* bet, long pstride, int L, int C, long n4,
+                                                            int act, float* y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long e = i * 4, r = e / C;
+  const int c = (int)(e - r * C), b = (int)(r / L);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + b * pstride + c), be = *reinterpret_cast<const f32x4*>(bet + b * pstride + c);
+  f32x4 a = v * ga + be;
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = silu_f(a[k]);
+  }
+  *reinterpret_cast<f32x4*>(y + e) = a;
+}
+// backward of the above: d' = act ? dy * SiLU'(x gamma + beta) : dy;  dx (+)= d' gamma;  dgamma[b][c] += sum_l d' x;  dbeta[b][c] += sum_l d'
+// (block = 64 channels x 4 row groups over a 64-row chunk of one sample, as film_bwd2_kernel)
+__global__ __launch_bounds__(256) void film_act_bwd_kernel(const float* d, const float* u, const float* gam, const float* bet, long pstride, int L, int C,
+                                                            int act, float* du, int accumulate, float* dgam, float* dbet) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, b = blockIdx.y;
+  const int l0 = blockIdx.z * 64, l1 = min(L, l0 + 64);
+  float sg = 0.f, sb = 0.f;
+  if (c < C) {
+    const float ga = gam[b * pstride + c], be = bet[b * pstride + c];
+    for (int l = l0 + rg; l < l1; l += 4) {
+      const long e = ((long)b * L + l) * C + c;
+      const float x = u[e];
+      float dd = d[e];
+      if (act) dd *= dsilu_f(x * ga + be);
+      sg += dd * x;
+      sb += dd;
+      du[e] = accumulate ? du[e] + dd * ga : dd * ga;
+    }
+  }
+  __shared__ float rs[256], rb[256];
+  rs[threadIdx.x] = sg;
+  rb[threadIdx.x] = sb;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const int x = threadIdx.x;
+    atomicAdd(dgam + b * pstride + c, rs[x] + rs[x + 64] + rs[x + 128] + rs[x + 192]);
+    atomicAdd(dbet + b * pstride + c, rb[x] + rb[x + 64] + rb[x + 128] + rb[x + 192]);
+  }
+}
+// y = LayerNorm(x) gamma[b] + beta[b]  (eps 1e-6, no LN affine; one wave per row; mean / rstd kept for the backward)
+__global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L,
+                                                           float* y, float* mean_out, float* rstd_out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const long pb = (row / L) * pstride;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = rsqrtf(v / C + 1e-6f);
+  for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c];
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+// backward: xn = (x - mean) rstd;  dn = dy gamma;  dx (+)= rstd (dn - mean(dn) - xn mean(dn xn));  dgamma[b][c] += sum_l dy xn;  dbeta += sum_l dy.
+// grid (ceil(L / 8), B): a block's 4 waves take 2 rows each of one sample (8-row chunks keep >= 1 000 blocks in flight at the
+// stroke levels; 64-row chunks ran at 43 us per launch), per-lane channel partial sums in registers (C <= 64 * 8), then one LDS
+// reduction and one atomic per channel and block.
+__global__ __launch_bounds__(256) void ln_film_bwd_kernel(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride,
+                                                           int L, int C, float* dx, int accumulate, float* dgam, float* dbet) {
+  constexpr int KMAX = 8;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+  const int l0 = blockIdx.x * 8, l1 = min(L, l0 + 8);
+  float sg[KMAX], sb[KMAX], ga[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { sg[k] = 0.f; sb[k] = 0.f; ga[k] = lane + 64 * k < C ? gam[b * pstride + lane + 64 * k] : 0.f; }
+  for (int l = l0 + w; l < l1; l += 4) {
+    const long row = (long)b * L + l;
+    const float mu = mean[row], rs = rstd[row];
+    float xn[KMAX], dn[KMAX], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = lane + 64 * k;
+      const bool in = c < C;
+      const float d = in ? dy[row * C + c] : 0.f;
+      xn[k] = in ? (x[row * C + c] - mu) * rs : 0.f;
+      dn[k] = d * ga[k];
+      sg[k] += d * xn[k];
+      sb[k] += d;
+      s1 += dn[k];
+      s2 += dn[k] * xn[k];
+    }
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= C; s2 /= C;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) {
+        const float v = rs * (dn[k] - s1 - xn[k] * s2);
+        dx[row * C + c] = accumulate ? dx[row * C + c] + v : v;
+      }
+    }
+  }
+  __shared__ float red[2][4][64 * KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { red[0][w][lane + 64 * k] = sg[k]; red[1][w][lane + 64 * k] = sb[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgam + b * pstride + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbet + b * pstride + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
 // All AffineTransformLayers' gamma / beta Linears (conditioning.py:16-18; 76 Linears of 32 inputs for num_layers = 2) as
 // ONE launch each way.  Column j of the table film[B][TOT] belongs to output channel woff[j] / 32 of some Linear: its weight
 // row starts at flat[woff[j]] (32 floats), its bias is flat[boff[j]] — the parameters stay where the state_dict puts them.
@@ -824,6 +940,26 @@ hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, l
 hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, long pstride, int B, int L, int C, float* du, int accumulate, float* dgam,
                             float* dbet, hipStream_t st) {
   hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
+  return hipGetLastError();
+}
+hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* y, hipStream_t st) {
+  const long n4 = (long)B * L * C / 4;
+  hipLaunchKernelGGL(film_act_fwd_kernel, dim3(nb(n4)), dim3(256), 0, st, x, gam, bet, pstride, L, C, n4, act, y);
+  return hipGetLastError();
+}
+hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
+                               int accumulate, float* dgam, float* dbet, hipStream_t st) {
+  hipLaunchKernelGGL(film_act_bwd_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, bet, pstride, L, C, act, du, accumulate, dgam, dbet);
+  return hipGetLastError();
+}
+hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, float* y, float* mean, float* rstd,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, y, mean, rstd);
+  return hipGetLastError();
+}
+hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,
+                              float* dx, int accumulate, float* dgam, float* dbet, hipStream_t st) {
+  hipLaunchKernelGGL(ln_film_bwd_kernel, dim3(nb(L, 8), B), dim3(256), 0, st, dy, x, mean, rstd, gam, pstride, L, C, dx, accumulate, dgam, dbet);
   return hipGetLastError();
 }
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st) {

@@ -221,7 +221,15 @@ class Tape:
         self.call("dhw_op_add", a.d.data_ptr(), b.d.data_ptr(), n, y.d.data_ptr(), 0)
 
         def bwd():
+            # d a = d b = d y.  y's gradient buffer is dead after this step (y's consumers ran before it in the reverse sweep), so
+            # the first input that has no gradient yet simply TAKES the buffer (later fan-in adds go into it); only the other input
+            # needs a copy / an add.  One launch per residual add in the backward instead of two.
+            taken = False
             for v in (a, b):
+                if v.g is None and not taken and not isinstance(v, _ViewVar):
+                    v.g = y.g
+                    taken = True
+                    continue
                 dv, acc = self.into(v)
                 self.call("dhw_op_add", y.g.data_ptr(), None, n, dv.data_ptr(), acc)
         self.record(y, bwd)
@@ -232,6 +240,9 @@ class Tape:
         y = Var(torch.empty_like(x.d))
         self.call("dhw_op_add_rows", x.d.data_ptr(), table.data_ptr(), B, R // B, Cc, y.d.data_ptr())
         def bwd():
+            if x.g is None and not isinstance(x, _ViewVar):
+                x.g = y.g          # (d x = d y, and y's buffer is dead after this step: take it instead of copying)
+                return
             dx, acc = self.into(x)
             self.call("dhw_op_add", y.g.data_ptr(), None, x.d.numel(), dx.data_ptr(), acc)
         self.record(y, bwd)
@@ -250,19 +261,39 @@ class Tape:
         self.record(y, bwd)
         return y
 
-    def film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int) -> Var:
-        """``film`` with gamma / beta taken from columns [col, col + C) of a [B, TOT] table (dhw_op_film_table)."""
+    def film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, act: bool = False) -> Var:
+        """``film`` with gamma / beta taken from columns [col, col + C) of a [B, TOT] table (dhw_op_film_table); ``act``: followed
+        by SiLU in the same pass (the ConvBlock's ``SiLU(affine(conv(.)))``, cnn.py:70-80) — one launch each way instead of two,
+        the FiLM output is recomputed in the backward instead of stored."""
         R, Cc = x.d.shape
         L, TOT = R // B, table.d.shape[1]
         y = Var(torch.empty_like(x.d))
         base = table.d.data_ptr()
-        self.call("dhw_op_film", x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, y.d.data_ptr())
+        self.call("dhw_op_film_act", x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act), y.d.data_ptr())
 
         def bwd():
             dx, acc = self.into(x)
             gbase = table.grad().data_ptr()
-            self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), base + col_g * _F, TOT, B, L, Cc, dx.data_ptr(), acc,
-                      gbase + col_g * _F, gbase + col_b * _F)
+            self.call("dhw_op_film_act_bwd", y.g.data_ptr(), x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act),
+                      dx.data_ptr(), acc, gbase + col_g * _F, gbase + col_b * _F)
+        self.record(y, bwd)
+        return y
+
+    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int) -> Var:
+        """LayerNorm followed by FiLM (every EncoderLayer / TextStyleEncoder pairs them: model.py:44-58, text_style.py:98-110) in one
+        pass each way; the normalised rows are recomputed in the backward from the saved mean / rstd."""
+        R, Cc = x.d.shape
+        L, TOT = R // B, table.d.shape[1]
+        y = Var(torch.empty_like(x.d))
+        mean, rstd = self.new(R), self.new(R)
+        base = table.d.data_ptr()
+        self.call("dhw_op_ln_film", x.d.data_ptr(), B, L, Cc, base + col_g * _F, base + col_b * _F, TOT, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+
+        def bwd():
+            dx, acc = self.into(x)
+            gbase = table.grad().data_ptr()
+            self.call("dhw_op_ln_film_bwd", y.g.data_ptr(), x.d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), base + col_g * _F, TOT, B, L, Cc,
+                      dx.data_ptr(), acc, gbase + col_g * _F, gbase + col_b * _F)
         self.record(y, bwd)
         return y
 
@@ -457,8 +488,12 @@ class TrainModel:
                                        sigma.grad().data_ptr()))
         self._film = table
 
-    def _affine(self, t, x, sigma, name, B):
-        return t.film_cols(x, self._film, *self.film_cols[name], B)
+    def _affine(self, t, x, sigma, name, B, act=False):
+        return t.film_cols(x, self._film, *self.film_cols[name], B, act)
+
+    def _ln_affine(self, t, x, sigma, name, B):
+        """affine(layernorm(x)) as one fused pass (LN statistics span at most 512 channels here)."""
+        return t.ln_film_cols(x, self._film, *self.film_cols[name], B)
 
     def _mha(self, t, q, k, v, name, B, H, mask=None):
         o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
@@ -468,9 +503,9 @@ class TrainModel:
         """cnn.py:64-87."""
         conv = lambda v, n: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L)   # noqa: E731
         skip = conv(x, "conv_skip")
-        h = self._affine(t, conv(t.silu(x), "conv1"), sigma, name + ".affine1", B)
-        h = self._affine(t, conv(t.silu(h), "conv2"), sigma, name + ".affine2", B)
-        h = self._affine(t, self._lin(t, t.silu(h), name + ".fc"), sigma, name + ".affine3", B)
+        h = self._affine(t, conv(t.silu(x), "conv1"), sigma, name + ".affine1", B, act=True)      # SiLU(affine1(.)) in one pass
+        h = self._affine(t, conv(h, "conv2"), sigma, name + ".affine2", B, act=True)
+        h = self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B)
         return t.add(h, skip)
 
     def _drop(self, t, v, B):
@@ -490,16 +525,16 @@ class TrainModel:
         """EncoderLayer.forward (model.py:36-58)."""
         d = x.d.shape[1]
         Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
-        tx = self._affine(t, t.layernorm(self._lin(t, t.silu(text), name + ".text_dense")), sigma, name + ".affine0", B)
+        tx = self._ln_affine(t, self._lin(t, t.silu(text), name + ".text_dense"), sigma, name + ".affine0", B)
         text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
-        x2 = t.add(self._affine(t, t.layernorm(self._drop(t, x2, B)), sigma, name + ".affine1", B), x)
+        x2 = t.add(self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B), x)
         x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)
         x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
-        x3 = self._affine(t, t.layernorm(t.add(x2, self._drop(t, x3, B))), sigma, name + ".affine2", B)
+        x3 = self._ln_affine(t, t.add(x2, self._drop(t, x3, B)), sigma, name + ".affine2", B)
         x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn"), B), x3)
-        return self._affine(t, t.layernorm(x4), sigma, name + ".affine3", B)
+        return self._ln_affine(t, x4, sigma, name + ".affine3", B)
 
     def _text_style(self, t, ids, style, sigma, keep, B):
         """TextStyleEncoder.forward (text_style.py:96-110)."""
@@ -508,12 +543,12 @@ class TrainModel:
         st = t.dropout(style, keep, self.STYLE_DROP)                          # [B, S, 1280]
         up = _ViewVar(st, (B * S * 5, st.d.shape[2] // 5))                      # reshape_up(., 5): a pure view of the same rows
         stf = self._ffn(t, up, n + ".style_ffn")
-        stf = self._affine(t, t.layernorm(stf), sigma, n + ".affine1", B)
+        stf = self._ln_affine(t, stf, sigma, n + ".affine1", B)
         tx = t.embedding(ids, self.p[n + ".emb.weight"])
-        tx = self._affine(t, t.layernorm(tx), sigma, n + ".affine2", B)
+        tx = self._ln_affine(t, tx, sigma, n + ".affine2", B)
         m = self._mha(t, tx, stf, stf, n + ".mha", B, 8)
-        tx = self._affine(t, t.layernorm(t.add(tx, m)), sigma, n + ".affine3", B)
-        return self._affine(t, t.layernorm(self._ffn(t, tx, n + ".text_ffn")), sigma, n + ".affine4", B)
+        tx = self._ln_affine(t, t.add(tx, m), sigma, n + ".affine3", B)
+        return self._ln_affine(t, self._ffn(t, tx, n + ".text_ffn"), sigma, n + ".affine4", B)
 
     # ---- forward / backward ----------------------------------------------------------------------------------------------
     def check_tokens(self, text: torch.Tensor):

@@ -105,6 +105,17 @@ int dhw_op_film(const float* x, const float* gamma, const float* beta, long long
 int dhw_op_film_bwd(const float* dy, const float* x, const float* gamma, long long pstride, int B, int L, int C, float* dx, int accumulate,
                     float* dgamma, float* dbeta /* += */, void* hip_stream);
 /* nn.LayerNorm(C, eps=1e-6, elementwise_affine=False) over each row; rstd [rows] is kept for the backward, which takes y */
+/* Fused element-wise chains (one HBM pass each way; the intermediate is recomputed in the backward):
+ *   film_act : y = act ? SiLU(x gamma[b] + beta[b]) : x gamma[b] + beta[b]     (conditioning.py:23-26 [+ the SiLU that follows in cnn.py:70-80])
+ *   ln_film  : y = LayerNorm(x) gamma[b] + beta[b]                             (model.py:25 + conditioning.py:23-26, as every EncoderLayer chains them)
+ * gamma / beta: per-sample rows [B][pstride]; the backward ADDS into dgamma / dbeta (same layout) and writes or adds dx. */
+int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* y, void* hip_stream);
+int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* dx,
+                        int accumulate, float* dgamma, float* dbeta, void* hip_stream);
+int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, float* y, float* mean, float* rstd,
+                   void* hip_stream);
+int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,
+                       float* dx, int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* hip_stream);
 int dhw_op_layernorm_bwd(const float* dy, const float* y, const float* rstd, long long rows, int C, float* dx, int accumulate, void* hip_stream);
 /* attention.py:16-22: P = softmax(S * scale + mask * -1e9) over `cols` keys; rows = B*H*Lq, mask [B][cols] or NULL */
