@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "enc_a_core.h"
+#include "enc16_core.h"
 
 namespace {
 
@@ -356,12 +357,32 @@ constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 
 template <typename T, int DM, int BM>
 constexpr bool fits() { return lds_a_bytes<T, DM, BM>() <= 160 * 1024 && lds_bc_bytes<T, DM, BM>() <= 160 * 1024 && (DM % 128 == 0 || BM >= 32); }
 
+// the specialised-wave form of enc_bc (+ chained enc_a) for the attention level (enc16_core.h): an experiment that lost its A/B
+// (profiles/r03_role_split_enclayer.log) — DHW_ENC16=1 selects it, the symmetric kernels are the default
+inline bool use_enc16() {
+  static const bool on = getenv("DHW_ENC16") && atoi(getenv("DHW_ENC16")) != 0;
+  return on;
+}
+template <int NEXT>
+hipError_t launch_enc16(const EncLayerParams& p, const EncChain& nx, hipStream_t st) {
+  static_assert(enc16::lds_bytes<NEXT>() <= 160 * 1024, "enc16 tiles do not fit LDS");
+  const int tiles = (p.Lk + 15) / 16;
+  hipLaunchKernelGGL((enc16::enc16_kernel<NEXT>), dim3(p.B * tiles), dim3(768), enc16::lds_bytes<NEXT>(), st, p, nx);
+  return hipGetLastError();
+}
+
 template <typename T, int DM, int BM>
 hipError_t launch_pair(const EncLayerParams& p, int which, hipStream_t st, const EncChain* chain) {
   if constexpr (!fits<T, DM, BM>()) {
     return hipErrorInvalidValue;
   } else {
   const int tiles = (p.Lk + BM - 1) / BM;
+  if constexpr (sizeof(T) == 2 && DM == 384 && BM == 16) {
+    if (which == 1 && !p.pool && !p.dbg && use_enc16()) {
+      if (!chain || !chain->mode) return launch_enc16<0>(p, EncChain{}, st);
+      if (chain->mode == 1 && chain->a.d == DM && !chain->a.x && !chain->a.dbg) return launch_enc16<1>(p, *chain, st);
+    }
+  }
   if (which == 0) {
     constexpr size_t lds = lds_a_bytes<T, DM, BM>();
     hipLaunchKernelGGL((enc_a_kernel<T, DM, BM>), dim3(p.B * tiles), dim3(512), lds, st, p);
@@ -428,6 +449,8 @@ hipError_t launch_bm(const EncLayerParams& p, int which, hipStream_t st, const E
 
 hipError_t enclayer_init() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc16::enc16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc16::enc16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = attr<bf16_t, 192, 64>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 256, 64>()) != hipSuccess) return e;
   if ((e = attr<bf16_t, 384, 64>()) != hipSuccess) return e;
