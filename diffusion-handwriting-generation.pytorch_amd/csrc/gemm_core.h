@@ -21,6 +21,9 @@ DHW_DEV void keep_alive(const Frag<float>& f) { asm volatile("" ::"v"(f.lo), "v"
 // ISSUES the first D k-chunks' loads, so a caller can start the NEXT stage's weight stream before it runs the
 // current stage's epilogue / barrier (the loads fly during the epilogue); run() consumes the ring.
 // ABL (diagnostic builds only, tools/bench_stage.cpp): bit0 = no MFMA, bit1 = no weight re-loads, bit2 = no LDS reads
+#ifndef DHW_EPI_PRIO
+#define DHW_EPI_PRIO 0   // experiment: wave priority between the end of a weight request and the next main loop (0 = off)
+#endif
 #ifndef DHW_ABL
 #define DHW_ABL 0   // diagnostic builds only (-DDHW_ABL=n): default ablation mask of every main loop
 #endif
@@ -130,9 +133,11 @@ struct WRing {
       asm volatile("" ::: "memory");
 #endif
     }
+    if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(DHW_EPI_PRIO);
   }
   template <int MT, int KT_, int ABL = DHW_ABL>
   DHW_DEV void run_s(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
+    if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     constexpr int ES = sizeof(T);
     constexpr int NR = KT_ > D ? KT_ - D : 0;   // steps that re-load their slot (chunk s + D exists)
     constexpr int G = NR / D;                   // of which whole groups of D run as a loop

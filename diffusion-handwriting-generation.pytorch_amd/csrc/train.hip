@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "dhw_common.h"
+#include <type_traits>
 #include "dhw_kernels.h"
 #include "heads_core.h"
 
@@ -386,17 +387,29 @@ DHW_DEV void st4(bf16_t* p, f32x4 v) {
 DHW_DEV Frag<float> ld_frag(const float* p) { Frag<float> f; f.lo = *reinterpret_cast<const f32x4*>(p); f.hi = *reinterpret_cast<const f32x4*>(p + 4); return f; }
 DHW_DEV Frag<bf16_t> ld_frag(const bf16_t* p) { return frag_load(p); }
 
-template <bool AM, bool BK, bool AV, bool BV, typename TS>
-__global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int tiles_n, int ksplit, int kslice) {
+DHW_DEV float frag_sum(const Frag<float>& f) { return ((f.lo[0] + f.lo[1]) + (f.lo[2] + f.lo[3])) + ((f.hi[0] + f.hi[1]) + (f.hi[2] + f.hi[3])); }
+DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)f.v[e];
+  return s;
+}
+
+// CV: the Conv1d features of the description are in use (taps, row shifts, lr).  The plain variant (every nn.Linear and the
+// attention products) compiles without their integer divisions and per-element range tests — the prologue of the general
+// form was ~1400 instructions with 19 divisions, as long as the whole K loop of a K = 128 GEMM.
+template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV>
+__global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
   constexpr int TR = tile_row<TS>;
   __shared__ __attribute__((aligned(16))) float smem[2 * GT * GS];      // operand tiles (TS), then the fp32 output tile
   TS* As = reinterpret_cast<TS*>(smem);
   TS* Bs = As + GT * TR;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
-  int bx = blockIdx.x;
-  const int ks = bx % ksplit; bx /= ksplit;
-  const int m0 = (bx / tiles_n) * GT, n0 = (bx % tiles_n) * GT;
-  const int z = blockIdx.y, zo = z / g.nzi, zi = z % g.nzi;
+  // grid: x = column tile, y = row tile, z = batch index * ksplit + K slice (each division only where its divisor is not 1)
+  const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT;
+  int ks = 0, z = blockIdx.z, zo = z, zi = 0;
+  if (ksplit > 1) { ks = z % ksplit; z /= ksplit; zo = z; }
+  if (g.nzi > 1) { zo = z / g.nzi; zi = z - zo * g.nzi; }
   const float* A = g.A + zo * g.sazo + zi * g.sazi;
   const float* B = g.B + zo * g.sbzo + zi * g.sbzi;
   float* C = g.C + zo * g.sczo + zi * g.sczi;
@@ -415,10 +428,10 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   constexpr int PD = 4;
   constexpr int NA = AV ? 2 : 8, NB = BV ? 2 : 8;      // loads per thread and step
   float rar[PD][8], rbr[PD][8];
-  const int Kt = g.K / g.taps;                  // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
-  const int b_sh = g.b_shift + zi * g.b_z_shift;
-  const unsigned lr_a = g.lr > 0 ? (unsigned)g.lr : 0x7fffffffu;           // no row shift: every row "in range"
-  const unsigned lr_b = b_sh != 0 ? (unsigned)g.lr : 0x7fffffffu;
+  const int Kt = CV ? g.K / g.taps : g.K;       // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
+  const int b_sh = CV ? g.b_shift + zi * g.b_z_shift : 0;
+  const unsigned lr_a = CV && g.lr > 0 ? (unsigned)g.lr : 0x7fffffffu;     // no row shift: every row "in range"
+  const unsigned lr_b = CV && b_sh != 0 ? (unsigned)g.lr : 0x7fffffffu;
   // local (tile) coordinates of load j: (am, ak) / (bn, bk); for a vector load the first of its 4 elements
   auto a_m = [&](int j) { return AV ? (AM ? 4 * (t & 15) : (t >> 3) + 32 * j) : (AM ? (t & 63) : (t >> 5) + 8 * j); };
   auto a_k = [&](int j) { return AV ? (AM ? (t >> 4) + 16 * j : 4 * (t & 7)) : (AM ? (t >> 6) + 4 * j : (t & 31)); };
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   for (int j = 0; j < NA; ++j) {
     const int m = m0 + a_m(j);
     mva[j] = m < g.M;                            // (a vector load's 4 rows / 4 k are valid together: M, K multiples of 4)
-    mla[j] = g.lr > 0 ? m % g.lr : 0;
+    mla[j] = CV && g.lr > 0 ? m % g.lr : 0;
     voa[j] = (unsigned)(m * (int)g.sam + a_k(j) * (int)g.sak);
   }
 #pragma unroll
@@ -439,58 +452,71 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
     const int n = n0 + b_n(j);
     nvb[j] = n < g.N;
     vob[j] = (unsigned)(b_k(j) * (int)g.sbk + n * (int)g.sbn);
-    klb[j] = b_sh != 0 ? (k_begin + b_k(j)) % g.lr : 0;   // row of the contraction index inside its sample (weight gradients)
+    klb[j] = CV && b_sh != 0 ? (k_begin + b_k(j)) % g.lr : 0;   // row of the contraction index inside its sample (weight gradients)
   }
   int k_next = k_begin;                          // load() is called for consecutive K steps
-  auto load = [&](float (&ra)[8], float (&rb)[8]) {
+  // Every load is issued unconditionally at a clamped (always valid) address and its validity bit is kept with the ring slot;
+  // stage() zeroes the invalid elements.  Written as `ok ? *p : 0` each load became a branch with s_waitcnt vmcnt(0) behind
+  // it, i.e. every K step waited for the loads it had just issued for three steps ahead: the prefetch ring hid nothing and a
+  // step cost one full L2 round trip (17-30 us per GEMM of 0.5 GFLOP; r3 ISA).
+  unsigned okm[PD];                              // bits 0..7: the A loads of the slot, bits 8..15: the B loads
+  auto load = [&](float (&ra)[8], float (&rb)[8], unsigned& okbits) {
     const int k0 = k_next;
     k_next += GK;
-    const int tap = g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
-    const int a_sh = g.a_shift + tap * g.a_tap_shift;
-    const int krem = k_end - k0;                 // <= 0 past the end of the slice: nothing is requested
+    const int tap = CV && g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
+    const int a_sh = CV ? g.a_shift + tap * g.a_tap_shift : 0;
+    const int krem = k_end - k0;                 // <= 0 past the end of the slice: every element invalid
     const float* Ab = A + (long)a_sh * g.sam + (long)kb * g.sak;
-    const float* Bb = B + tap * g.sbt + (long)(kb + b_sh) * g.sbk;
+    const float* Bb = B + (CV ? tap * g.sbt : 0) + (long)(kb + b_sh) * g.sbk;
+    unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const bool ok = mva[j] && a_k(j) < krem && (unsigned)(mla[j] + a_sh) < lr_a;
+      const bool ok = mva[j] && a_k(j) < krem && (!CV || (unsigned)(mla[j] + a_sh) < lr_a);
+      bits |= (ok ? 1u : 0u) << j;
+      const float* src = ok ? Ab + voa[j] : A;
       if constexpr (AV) {
-        const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(Ab + voa[j]) : (f32x4){0, 0, 0, 0};
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
         ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
       } else {
-        ra[j] = ok ? Ab[voa[j]] : 0.f;
+        ra[j] = *src;
       }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const bool okb = nvb[j] && b_k(j) < krem && (unsigned)(klb[j] + b_sh) < lr_b;
+      const bool okb = nvb[j] && b_k(j) < krem && (!CV || (unsigned)(klb[j] + b_sh) < lr_b);
+      bits |= (okb ? 1u : 0u) << (8 + j);
+      const float* src = okb ? Bb + vob[j] : B;
       if constexpr (BV) {
-        const f32x4 v = okb ? *reinterpret_cast<const f32x4*>(Bb + vob[j]) : (f32x4){0, 0, 0, 0};
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
         rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
       } else {
-        rb[j] = okb ? Bb[vob[j]] : 0.f;
+        rb[j] = *src;
       }
-      if (b_sh != 0) {                           // uniform
+      if (CV && b_sh != 0) {                     // uniform
         klb[j] += GK;
-        while (klb[j] >= g.lr) klb[j] -= g.lr;
+        if (g.lr >= GK) klb[j] -= klb[j] >= g.lr ? g.lr : 0;   // (uniform; samples shorter than a K step: the general form)
+        else klb[j] %= g.lr;
       }
     }
+    okbits = bits;
   };
-  auto stage = [&](const float (&ra)[8], const float (&rb)[8]) {
+  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits) {
+    auto z = [&](int bit, float v) { return (bits >> bit) & 1u ? v : 0.f; };
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      if constexpr (AV && !AM) st4(As + a_m(j) * TR + a_k(j), (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]});
+      if constexpr (AV && !AM) st4(As + a_m(j) * TR + a_k(j), (f32x4){z(j, ra[4 * j]), z(j, ra[4 * j + 1]), z(j, ra[4 * j + 2]), z(j, ra[4 * j + 3])});
       else if constexpr (AV) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) As[(a_m(j) + e) * TR + a_k(j)] = from_f<TS>(ra[4 * j + e]);
-      } else As[a_m(j) * TR + a_k(j)] = from_f<TS>(ra[j]);
+        for (int e = 0; e < 4; ++e) As[(a_m(j) + e) * TR + a_k(j)] = from_f<TS>(z(j, ra[4 * j + e]));
+      } else As[a_m(j) * TR + a_k(j)] = from_f<TS>(z(j, ra[j]));
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if constexpr (BV && BK) st4(Bs + b_n(j) * TR + b_k(j), (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]});
+      if constexpr (BV && BK) st4(Bs + b_n(j) * TR + b_k(j), (f32x4){z(8 + j, rb[4 * j]), z(8 + j, rb[4 * j + 1]), z(8 + j, rb[4 * j + 2]), z(8 + j, rb[4 * j + 3])});
       else if constexpr (BV) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[(b_n(j) + e) * TR + b_k(j)] = from_f<TS>(rb[4 * j + e]);
-      } else Bs[b_n(j) * TR + b_k(j)] = from_f<TS>(rb[j]);
+        for (int e = 0; e < 4; ++e) Bs[(b_n(j) + e) * TR + b_k(j)] = from_f<TS>(z(8 + j, rb[4 * j + e]));
+      } else Bs[b_n(j) * TR + b_k(j)] = from_f<TS>(z(8 + j, rb[j]));
     }
   };
 
@@ -502,34 +528,64 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ti
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
 #pragma unroll
-  for (int p = 0; p < PD - 1; ++p) load(rar[p], rbr[p]);   // (elements past k_end are not requested)
-  for (int kb = k_begin; kb < k_end; kb += PD * GK) {
+  for (int p = 0; p < PD - 1; ++p) load(rar[p], rbr[p], okm[p]);
+  // one K step with ring slot p (compile-time): request step + PD - 1, stage this step's operands, contract
+  // bias gradient riding on the weight-gradient GEMM (g.rowsum): the waves that hold the A fragments of the first column tile
+  // of batch 0 also add them up — 16 additions per lane and step instead of a second pass over dy (colsum_kernel: one launch
+  // per Linear / Conv1d, 8.7 % of the update)
+  const bool rs_on = g.rowsum != nullptr && n0 == 0 && z == 0 && wn == 0;   // (wave-uniform)
+  float rs[2] = {0.f, 0.f};
+  auto kstep = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    load(rar[(p + PD - 1) % PD], rbr[(p + PD - 1) % PD], okm[(p + PD - 1) % PD]);   // (past k_end: clamped addresses, all-zero)
+    __syncthreads();        // the previous step's fragment reads are done
+    stage(rar[p], rbr[p], okm[p]);
+    __syncthreads();
+    Frag<TS> fa[2], fb[2];
 #pragma unroll
-    for (int p = 0; p < PD; ++p) {
-      const int k0 = kb + p * GK;
-      if (k0 < k_end) {         // uniform over the workgroup
-        load(rar[(p + PD - 1) % PD], rbr[(p + PD - 1) % PD]);
-        __syncthreads();        // the previous step's fragment reads are done
-        stage(rar[p], rbr[p]);
-        __syncthreads();
-        Frag<TS> fa[2], fb[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          fa[a] = ld_frag(As + (wm + 16 * a + i) * TR + 8 * q);
-          fb[a] = ld_frag(Bs + (wn + 16 * a + i) * TR + 8 * q);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
-      }
+    for (int a = 0; a < 2; ++a) {
+      fa[a] = ld_frag(As + (wm + 16 * a + i) * TR + 8 * q);
+      fb[a] = ld_frag(Bs + (wn + 16 * a + i) * TR + 8 * q);
     }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
+    if (rs_on) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) rs[a] += frag_sum(fa[a]);
+    }
+  };
+  // Steady state: PD steps per iteration with NO branch inside — hipcc's s_waitcnt insertion loses track of which loads have
+  // landed at every control-flow merge and then waits for (nearly) all of them before it reuses a ring register, which
+  // serialises the ring just like the vmcnt(0) above.  The remaining steps (up to PD, the last one partial) follow with their tests.
+  int kb = k_begin;
+  for (; kb + PD * GK <= k_end; kb += PD * GK) {
+    kstep(std::integral_constant<int, 0>{});
+    kstep(std::integral_constant<int, 1>{});
+    kstep(std::integral_constant<int, 2>{});
+    kstep(std::integral_constant<int, 3>{});
   }
+  static_assert(PD == 4, "the unrolled ring above");
+  if (kb < k_end) kstep(std::integral_constant<int, 0>{});
+  if (kb + GK < k_end) kstep(std::integral_constant<int, 1>{});
+  if (kb + 2 * GK < k_end) kstep(std::integral_constant<int, 2>{});
+  if (kb + 3 * GK < k_end) kstep(std::integral_constant<int, 3>{});   // (fewer than PD * GK elements left can still be PD steps, the last one partial)
 
   // acc[a][b][r] = C[m0 + wm + 16 a + 4 q + r][n0 + wn + 16 b + i].  The tile goes through LDS so that a wave-instruction
   // writes 64 consecutive columns of one row (256 contiguous bytes when scn = 1) instead of 16 columns of 4 rows: fp32
   // atomics run at their full rate only for whole 256-byte wave-instructions (MI355X_MICROARCH.md, atomics), and the split-K
   // weight gradients are made of them.
+  if (rs_on) {   // lanes i, i + 16, i + 32, i + 48 hold the four k-quarters of row wm + 16 a + i
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float v = rs[a];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int m = m0 + wm + 16 * a + i;
+      if (q == 0 && m < g.M) atomicAdd(g.rowsum + m, v);
+    }
+  }
   constexpr int CS = GT + 1;
   static_assert(GT * CS <= 2 * GT * GS, "the output tile reuses the operand tiles");
   __syncthreads();
@@ -895,7 +951,8 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   if (ksplit < 1) ksplit = 1;
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;
-  const dim3 grid((unsigned)(tiles_m * tiles_n * ksplit), g.nzo * g.nzi), block(256);
+  if (tiles_m > 65535 || (long)g.nzo * g.nzi * ksplit > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)(g.nzo * g.nzi * ksplit)), block(256);
   // lanes run along the index whose stride is the smaller one; 16-byte loads where that stride is 1 and everything is aligned
   const bool am = std::llabs(g.sam) < std::llabs(g.sak), bk = std::llabs(g.sbk) < std::llabs(g.sbn);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -907,13 +964,15 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   bv = bv && al16(g.B) && g.sbzo % 4 == 0 && g.sbzi % 4 == 0 && g.sbt % 4 == 0;
   static const bool novec = [] { const char* e = getenv("DHW_SGEMM_SCALAR"); return e && *e == '1'; }();
   if (novec) av = bv = false;
-  using KFn = void (*)(const OpGemm, int, int, int);
-#define DHW_SG4(AM_, BK_, TS_) sgemm_tiled_kernel<AM_, BK_, false, false, TS_>, sgemm_tiled_kernel<AM_, BK_, false, true, TS_>, \
-                               sgemm_tiled_kernel<AM_, BK_, true, false, TS_>, sgemm_tiled_kernel<AM_, BK_, true, true, TS_>
-  static const KFn variants[32] = {DHW_SG4(false, false, float), DHW_SG4(false, true, float), DHW_SG4(true, false, float), DHW_SG4(true, true, float),
-                                   DHW_SG4(false, false, bf16_t), DHW_SG4(false, true, bf16_t), DHW_SG4(true, false, bf16_t), DHW_SG4(true, true, bf16_t)};
+  const bool cv = g.lr > 0 || g.taps > 1 || g.a_shift || g.a_tap_shift || g.b_shift || g.b_z_shift;
+  using KFn = void (*)(const OpGemm, int, int);
+#define DHW_SG4(AM_, BK_, TS_, CV_) sgemm_tiled_kernel<AM_, BK_, false, false, TS_, CV_>, sgemm_tiled_kernel<AM_, BK_, false, true, TS_, CV_>, \
+                                    sgemm_tiled_kernel<AM_, BK_, true, false, TS_, CV_>, sgemm_tiled_kernel<AM_, BK_, true, true, TS_, CV_>
+#define DHW_SG16(TS_, CV_) DHW_SG4(false, false, TS_, CV_), DHW_SG4(false, true, TS_, CV_), DHW_SG4(true, false, TS_, CV_), DHW_SG4(true, true, TS_, CV_)
+  static const KFn variants[64] = {DHW_SG16(float, false), DHW_SG16(bf16_t, false), DHW_SG16(float, true), DHW_SG16(bf16_t, true)};
+#undef DHW_SG16
 #undef DHW_SG4
-  hipLaunchKernelGGL(variants[(g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, tiles_n, ksplit, kslice);
+  hipLaunchKernelGGL(variants[(cv ? 32 : 0) + (g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, ksplit, kslice);
   return hipGetLastError();
 }
 hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {

@@ -14,6 +14,7 @@ trained one can be handed straight to ``dhg_amd.DiffusionModel`` for sampling.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -24,6 +25,10 @@ from .train import Adam, _stream, _tcheck, allreduce_grads, get_alphas, loss_fn,
 
 _F = 4  # bytes per element
 
+
+# DHW_TRAIN_WGRAD_SIDE=1: weight-gradient GEMMs on the tape's side stream (parallel hipGraph branches beside the data-gradient
+# chain).  Measured slower (9.93 vs 9.12 ms per update, r3): the GEMMs already fill the CUs, the branches only interleave them.
+WGRAD_SIDE = os.environ.get("DHW_TRAIN_WGRAD_SIDE", "0") == "1"
 
 class Var:
     """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient.  ``leaf``: a network input
@@ -102,7 +107,8 @@ class Tape:
         self.held = []
 
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
-             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False):
+             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False,
+             rowsum=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
 
@@ -120,7 +126,8 @@ class Tape:
         d = _lib.GemmDesc(A.data_ptr() + a_off * _F, sam, sak, za[0], za[1], a_shift, a_tap_shift,
                           Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
-                          M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16)
+                          M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
+                          rowsum.data_ptr() if rowsum is not None else None)
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
@@ -157,10 +164,9 @@ class Tape:
                 dx, acc = self.into(x)
                 self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)             # dx (+)= dy W
             dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
-            self.fork(dy, x.d)
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True)         # dW += dy^T x
-            if b is not None:
-                self.call("dhw_op_colsum", dy.data_ptr(), R, N, db.data_ptr(), side=True)
+            if WGRAD_SIDE:
+                self.fork(dy, x.d)
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, rowsum=db, side=WGRAD_SIDE)   # dW += dy^T x, db += column sums of dy
         self.record(y, bwd)
         return y
 
@@ -181,18 +187,19 @@ class Tape:
         def bwd():
             dy, dW, db = y.g, W.grad(), b.grad()
             dx, acc = self.into(x)
-            self.fork(dy, x.d)
+            if WGRAD_SIDE:
+                self.fork(dy, x.d)
             # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
             if merged:
                 self.gemm(dy, 0, Cout, 1, W.d, 0, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
                           sbt=1, lr=L)
                 self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, Cin * 3, 3, Cout, Cin, R, acc=True, nzi=3, zc=(0, 1), b_shift=-1,
-                          b_z_shift=1, lr=L)                                       # the taps as the inner batch index
+                          b_z_shift=1, lr=L, rowsum=db, side=WGRAD_SIDE)                            # the taps as the inner batch index; db rides along
             else:
                 for t in range(3):
                     self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
-                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L)
-            self.call("dhw_op_colsum", dy.data_ptr(), R, Cout, db.data_ptr(), side=True)
+                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L,
+                              rowsum=db if t == 1 else None, side=WGRAD_SIDE)
         self.record(y, bwd)
         return y
 

@@ -90,6 +90,8 @@ typedef struct {
   const float* bias; float alpha; int accumulate;
   int bf16;   /* 0: exact-f32 MFMA.  1: the operands (fp32 in memory) are rounded to bf16 on their way into LDS and contracted on
                  the bf16 MFMA with fp32 accumulation — mixed-precision training with fp32 master weights */
+  float* rowsum;   /* NULL, or [M]: rowsum[m] += sum_k A(0,m,k) (batch z = 0 only) — the bias gradient of a Linear / Conv1d comes out
+                      of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum) */
 } dhw_gemm_desc;
 
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
