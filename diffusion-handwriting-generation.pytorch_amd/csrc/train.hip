@@ -401,9 +401,13 @@ DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
 template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV>
 __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
   constexpr int TR = tile_row<TS>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * GT * GS];      // operand tiles (TS), then the fp32 output tile
+  // two buffers of operand tiles (TS) — step s is contracted out of one while step s + 1 is staged into the other — then the
+  // fp32 output tile
+  constexpr int BUF = 2 * GT * GS;                                       // floats per buffer (sized for TS = float)
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   TS* As = reinterpret_cast<TS*>(smem);
   TS* Bs = As + GT * TR;
+  constexpr int BUFE = BUF * (int)(sizeof(float) / sizeof(TS));          // the same in elements of TS
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
   // grid: x = column tile, y = row tile, z = batch index * ksplit + K slice (each division only where its divisor is not 1)
   const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // Vector form (AV / BV: the lane index has stride exactly 1 and everything is 16-byte aligned), two 16-byte loads:
   //   A: AM: m = 4 (t & 15) .. +3 at k = (t >> 4) + 16 jj;     else: k = 4 (t & 7) .. +3 of row m = (t >> 3) + 32 jj
   //   B: BK: k = 4 (t & 7) .. +3 of column n = (t >> 3) + 32 jj;   else: n = 4 (t & 15) .. +3 at k = (t >> 4) + 16 jj
-  // PD K steps of operands are kept in flight in registers; the loads of step s + PD - 1 are issued before step s is staged.
+  // PD K steps of operands are kept in flight in registers (kstep below).
   // Address arithmetic is kept out of the K loop (it was as long as the MFMA work): each element's offset inside its operand
   // is a per-thread 32-bit constant, everything that changes from step to step (k position, tap, row shift) is uniform and
   // goes into the scalar base pointer; the per-step vector work is the validity compares.
@@ -500,7 +504,9 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
     okbits = bits;
   };
-  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits) {
+  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits, int buf) {
+    TS* As = reinterpret_cast<TS*>(smem) + buf * BUFE;
+    TS* Bs = As + GT * TR;
     auto z = [&](int bit, float v) { return (bits >> bit) & 1u ? v : 0.f; };
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -528,33 +534,38 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
 #pragma unroll
-  for (int p = 0; p < PD - 1; ++p) load(rar[p], rbr[p], okm[p]);
-  // one K step with ring slot p (compile-time): request step + PD - 1, stage this step's operands, contract
+  for (int p = 0; p < PD; ++p) load(rar[p], rbr[p], okm[p]);
   // bias gradient riding on the weight-gradient GEMM (g.rowsum): the waves that hold the A fragments of the first column tile
   // of batch 0 also add them up — 16 additions per lane and step instead of a second pass over dy (colsum_kernel: one launch
   // per Linear / Conv1d, 8.7 % of the update)
   const bool rs_on = g.rowsum != nullptr && n0 == 0 && z == 0 && wn == 0;   // (wave-uniform)
   float rs[2] = {0.f, 0.f};
+  // Step s (ring slot p = s mod PD, LDS buffer p & 1): request step s + PD - 1, read this step's fragments, and stage step
+  // s + 1 into the other buffer between the two halves of the MFMA work — the matrix pipe runs while the wave does the
+  // staging's selects and LDS writes; ONE barrier per step (everybody's reads of this buffer and writes of the next are done).
+  stage(rar[0], rbr[0], okm[0], 0);
+  __syncthreads();
   auto kstep = [&](auto pc) {
-    constexpr int p = decltype(pc)::value;
-    load(rar[(p + PD - 1) % PD], rbr[(p + PD - 1) % PD], okm[(p + PD - 1) % PD]);   // (past k_end: clamped addresses, all-zero)
-    __syncthreads();        // the previous step's fragment reads are done
-    stage(rar[p], rbr[p], okm[p]);
-    __syncthreads();
+    constexpr int p = decltype(pc)::value, pn = (p + 1) % PD;
+    const TS* Ac = reinterpret_cast<const TS*>(smem) + (p & 1) * BUFE;
+    const TS* Bc = Ac + GT * TR;
+    load(rar[p], rbr[p], okm[p]);   // slot p was staged one step ago: it takes step s + PD (past k_end: clamped, all-zero)
     Frag<TS> fa[2], fb[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      fa[a] = ld_frag(As + (wm + 16 * a + i) * TR + 8 * q);
-      fb[a] = ld_frag(Bs + (wn + 16 * a + i) * TR + 8 * q);
+      fa[a] = ld_frag(Ac + (wm + 16 * a + i) * TR + 8 * q);
+      fb[a] = ld_frag(Bc + (wn + 16 * a + i) * TR + 8 * q);
     }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
+    mma32(acc[0][0], fa[0], fb[0]);
+    mma32(acc[0][1], fa[0], fb[1]);
+    stage(rar[pn], rbr[pn], okm[pn], pn & 1);
+    mma32(acc[1][0], fa[1], fb[0]);
+    mma32(acc[1][1], fa[1], fb[1]);
     if (rs_on) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) rs[a] += frag_sum(fa[a]);
     }
+    __syncthreads();
   };
   // Steady state: PD steps per iteration with NO branch inside — hipcc's s_waitcnt insertion loses track of which loads have
   // landed at every control-flow merge and then waits for (nearly) all of them before it reuses a ring register, which
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
   }
   constexpr int CS = GT + 1;
-  static_assert(GT * CS <= 2 * GT * GS, "the output tile reuses the operand tiles");
+  static_assert(GT * CS <= 2 * BUF, "the output tile reuses the operand tiles");
   __syncthreads();
   float* Cs = smem;
 #pragma unroll
