@@ -171,34 +171,38 @@ class Tape:
         return y
 
     def conv3(self, x: Var, W: Var, b: Var, L: int) -> Var:
-        """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout]."""
+        """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
+        have any strides: TrainModel keeps the Conv1d weights as [tap][Cout][Cin] in memory (unit stride along Cin), which makes the
+        weight the 16-byte-load operand of all three GEMMs; a torch-contiguous W works too (scalar loads, stride-3 stores)."""
         R, Cin = x.d.shape
         Cout = W.d.shape[0]
+        sco, sci, st = W.d.stride()
         y = Var(self.new(R, Cout))
         merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
         if merged:
-            self.gemm(x.d, 0, Cin, 1, W.d, 0, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
-                      sbt=1, lr=L)
+            self.gemm(x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
+                      sbt=st, lr=L)
         else:
             for t in range(3):
-                self.gemm(x.d, 0, Cin, 1, W.d, t, 3, Cin * 3, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
+                self.gemm(x.d, 0, Cin, 1, W.d, t * st, sci, sco, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
                           a_shift=t - 1, lr=L)
 
         def bwd():
             dy, dW, db = y.g, W.grad(), b.grad()
+            gco, gci, gt = dW.stride()
             dx, acc = self.into(x)
             if WGRAD_SIDE:
                 self.fork(dy, x.d)
             # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
             if merged:
-                self.gemm(dy, 0, Cout, 1, W.d, 0, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
-                          sbt=1, lr=L)
-                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, Cin * 3, 3, Cout, Cin, R, acc=True, nzi=3, zc=(0, 1), b_shift=-1,
+                self.gemm(dy, 0, Cout, 1, W.d, 0, sco, sci, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
+                          sbt=st, lr=L)
+                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, gco, gci, Cout, Cin, R, acc=True, nzi=3, zc=(0, gt), b_shift=-1,
                           b_z_shift=1, lr=L, rowsum=db, side=WGRAD_SIDE)                            # the taps as the inner batch index; db rides along
             else:
                 for t in range(3):
-                    self.gemm(dy, 0, Cout, 1, W.d, t, Cin * 3, 3, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
-                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t, Cin * 3, 3, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L,
+                    self.gemm(dy, 0, Cout, 1, W.d, t * st, sco, sci, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
+                    self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t * gt, gco, gci, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L,
                               rowsum=db if t == 1 else None, side=WGRAD_SIDE)
         self.record(y, bwd)
         return y
@@ -413,9 +417,15 @@ class TrainModel:
         self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=self.dev)
         self._masks, self._site = None, 3
         self.names = list(state_dict.keys())
-        host = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).detach().to("cpu", torch.float32).reshape(-1)
-                for k, v in state_dict.items()}
         shapes = {k: tuple(np.shape(v)) for k, v in state_dict.items()}
+        # Conv1d weights [Cout, Cin, 3] are kept as [tap][Cout][Cin] in the flat buffers (unit stride along Cin: the weight is then
+        # the 16-byte-load operand of the forward, data-gradient and weight-gradient GEMMs alike; in torch's layout it was a stride-3
+        # gather / scatter).  Their named views are the permuted views, so shapes and values are the reference's everywhere.
+        conv_w = {k for k in shapes if len(shapes[k]) == 3 and shapes[k][2] == 3}
+        host = {}
+        for k, v in state_dict.items():
+            h = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).detach().to("cpu", torch.float32)
+            host[k] = (h.permute(2, 0, 1).contiguous() if k in conv_w else h).reshape(-1)
         # ONE flat fp32 buffer for all parameters and one for all gradients (40 MB each): a single memset clears the
         # gradients, a single kernel pair clips and applies Adam, a single all-reduce averages them across ranks.
         self.flat = torch.cat([host[k] for k in self.names]).to(self.dev)
@@ -423,8 +433,9 @@ class TrainModel:
         self.p, self.offset, off = {}, {}, 0
         for k in self.names:
             n = host[k].numel()
-            v = Var(self.flat[off:off + n].view(shapes[k]))
-            v.g = self.flat_grad[off:off + n].view(shapes[k])
+            view = (lambda buf: buf[off:off + n].view(3, *shapes[k][:2]).permute(1, 2, 0)) if k in conv_w else (lambda buf: buf[off:off + n].view(shapes[k]))
+            v = Var(view(self.flat))
+            v.g = view(self.flat_grad)
             self.p[k] = v
             self.offset[k] = off
             off += n
@@ -452,7 +463,8 @@ class TrainModel:
 
     # ---- parameters ------------------------------------------------------------------------------------------------------
     def parameters(self):
-        """The flat parameter buffer (every named parameter is a view into it, in state_dict order)."""
+        """The flat parameter buffer (every named parameter is a view into it, in state_dict order; Conv1d weights as
+        [tap][Cout][Cin], their named views permuted back to [Cout, Cin, 3])."""
         return [self.flat]
 
     def grads(self):
