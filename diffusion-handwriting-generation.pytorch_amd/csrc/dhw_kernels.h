@@ -229,6 +229,7 @@ struct OpGemm {
   int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate, bf16;
   float* rowsum;   // or null: rowsum[m] += sum_k A(0,m,k) (batch z = 0) — a Linear / Conv1d bias gradient out of its weight-gradient GEMM
+  unsigned long long* stamps;   // diagnostics only (tools/bench_sgemm.cpp, -DDHW_STAMPS builds): s_memrealtime of one workgroup's phases, or null
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
 hipError_t launch_film_table(int dir, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int TOT, float* film,

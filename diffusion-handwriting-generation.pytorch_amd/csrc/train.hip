@@ -398,8 +398,14 @@ DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
 // CV: the Conv1d features of the description are in use (taps, row shifts, lr).  The plain variant (every nn.Linear and the
 // attention products) compiles without their integer divisions and per-element range tests — the prologue of the general
 // form was ~1400 instructions with 19 divisions, as long as the whole K loop of a K = 128 GEMM.
+#ifdef DHW_STAMPS
+#define SG_STAMP(slot) do { if (g.stamps && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && threadIdx.x == 0) g.stamps[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SG_STAMP(slot) do { } while (0)
+#endif
 template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV>
 __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
+  SG_STAMP(0);
   constexpr int TR = tile_row<TS>;
   // two buffers of operand tiles (TS) — step s is contracted out of one while step s + 1 is staged into the other — then the
   // fp32 output tile
@@ -464,7 +470,38 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // it, i.e. every K step waited for the loads it had just issued for three steps ahead: the prefetch ring hid nothing and a
   // step cost one full L2 round trip (17-30 us per GEMM of 0.5 GFLOP; r3 ISA).
   unsigned okm[PD];                              // bits 0..7: the A loads of the slot, bits 8..15: the B loads
-  auto load = [&](float (&ra)[8], float (&rb)[8], unsigned& okbits) {
+  // FAST (interior tile of a plain GEMM whose K slice is whole steps — uniform per workgroup): nothing per element at all, the
+  // step's base pointers are scalar (past the end of the slice: the first step again — valid memory, never contracted).  The
+  // per-element selects, compares and 64-bit address adds of the general form are ~100 VALU instructions per step, and VALU
+  // issue stalls the same SIMD's MFMA pipe: a step took 0.85-0.95 us against 0.43 us of MFMA work (tools/bench_sgemm stamps).
+  auto load = [&](float (&ra)[8], float (&rb)[8], unsigned& okbits, auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
+    if constexpr (FAST) {
+      const int k0 = k_next < k_end ? k_next : k_begin;
+      k_next += GK;
+      const float* Ab = A + (long)k0 * g.sak;
+      const float* Bb = B + (long)k0 * g.sbk;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        if constexpr (AV) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + voa[j]);
+          ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
+        } else {
+          ra[j] = Ab[voa[j]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if constexpr (BV) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Bb + vob[j]);
+          rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+        } else {
+          rb[j] = Bb[vob[j]];
+        }
+      }
+      okbits = 0xffffu;
+      return;
+    }
     const int k0 = k_next;
     k_next += GK;
     const int tap = CV && g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
@@ -504,10 +541,11 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
     okbits = bits;
   };
-  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits, int buf) {
+  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits, int buf, auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
     TS* As = reinterpret_cast<TS*>(smem) + buf * BUFE;
     TS* Bs = As + GT * TR;
-    auto z = [&](int bit, float v) { return (bits >> bit) & 1u ? v : 0.f; };
+    auto z = [&](int bit, float v) { if constexpr (FAST) return v; else return (bits >> bit) & 1u ? v : 0.f; };
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       if constexpr (AV && !AM) st4(As + a_m(j) * TR + a_k(j), (f32x4){z(j, ra[4 * j]), z(j, ra[4 * j + 1]), z(j, ra[4 * j + 2]), z(j, ra[4 * j + 3])});
@@ -533,60 +571,71 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
-#pragma unroll
-  for (int p = 0; p < PD; ++p) load(rar[p], rbr[p], okm[p]);
   // bias gradient riding on the weight-gradient GEMM (g.rowsum): the waves that hold the A fragments of the first column tile
   // of batch 0 also add them up — 16 additions per lane and step instead of a second pass over dy (colsum_kernel: one launch
   // per Linear / Conv1d, 8.7 % of the update)
   const bool rs_on = g.rowsum != nullptr && n0 == 0 && z == 0 && wn == 0;   // (wave-uniform)
   float rs[2] = {0.f, 0.f};
-  // Step s (ring slot p = s mod PD, LDS buffer p & 1): request step s + PD - 1, read this step's fragments, and stage step
+  // Step s (ring slot p = s mod PD, LDS buffer p & 1): request step s + PD, read this step's fragments, and stage step
   // s + 1 into the other buffer between the two halves of the MFMA work — the matrix pipe runs while the wave does the
   // staging's selects and LDS writes; ONE barrier per step (everybody's reads of this buffer and writes of the next are done).
-  stage(rar[0], rbr[0], okm[0], 0);
-  __syncthreads();
-  auto kstep = [&](auto pc) {
-    constexpr int p = decltype(pc)::value, pn = (p + 1) % PD;
-    const TS* Ac = reinterpret_cast<const TS*>(smem) + (p & 1) * BUFE;
-    const TS* Bc = Ac + GT * TR;
-    load(rar[p], rbr[p], okm[p]);   // slot p was staged one step ago: it takes step s + PD (past k_end: clamped, all-zero)
-    Frag<TS> fa[2], fb[2];
+  // (Fragments of step s + 1 read ahead into a second register set, tile s + 2 staged meanwhile: no faster per step and
+  // 8.1 vs 7.6 ms per update for the registers it costs.)
+  auto run = [&](auto fastc) {
+    SG_STAMP(1);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      fa[a] = ld_frag(Ac + (wm + 16 * a + i) * TR + 8 * q);
-      fb[a] = ld_frag(Bc + (wn + 16 * a + i) * TR + 8 * q);
-    }
-    mma32(acc[0][0], fa[0], fb[0]);
-    mma32(acc[0][1], fa[0], fb[1]);
-    stage(rar[pn], rbr[pn], okm[pn], pn & 1);
-    mma32(acc[1][0], fa[1], fb[0]);
-    mma32(acc[1][1], fa[1], fb[1]);
-    if (rs_on) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a) rs[a] += frag_sum(fa[a]);
-    }
+    for (int p = 0; p < PD; ++p) load(rar[p], rbr[p], okm[p], fastc);
+    SG_STAMP(2);
+    stage(rar[0], rbr[0], okm[0], 0, fastc);
     __syncthreads();
+    SG_STAMP(3);
+    auto kstep = [&](auto pc) {
+      constexpr int p = decltype(pc)::value, pn = (p + 1) % PD;
+      const TS* Ac = reinterpret_cast<const TS*>(smem) + (p & 1) * BUFE;
+      const TS* Bc = Ac + GT * TR;
+      load(rar[p], rbr[p], okm[p], fastc);   // slot p was staged one step ago: it takes step s + PD (past k_end: clamped, all-zero)
+      Frag<TS> fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        fa[a] = ld_frag(Ac + (wm + 16 * a + i) * TR + 8 * q);
+        fb[a] = ld_frag(Bc + (wn + 16 * a + i) * TR + 8 * q);
+      }
+      mma32(acc[0][0], fa[0], fb[0]);
+      mma32(acc[0][1], fa[0], fb[1]);
+      stage(rar[pn], rbr[pn], okm[pn], pn & 1, fastc);
+      mma32(acc[1][0], fa[1], fb[0]);
+      mma32(acc[1][1], fa[1], fb[1]);
+      if (rs_on) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) rs[a] += frag_sum(fa[a]);
+      }
+      __syncthreads();
+    };
+    // Steady state: PD steps per iteration with NO branch inside — hipcc's s_waitcnt insertion loses track of which loads have
+    // landed at every control-flow merge and then waits for (nearly) all of them before it reuses a ring register, which
+    // serialises the ring just like the vmcnt(0) above.  The remaining steps (up to PD, the last one partial) follow with their tests.
+    int kb = k_begin;
+    for (; kb + PD * GK <= k_end; kb += PD * GK) {
+      kstep(std::integral_constant<int, 0>{});
+      kstep(std::integral_constant<int, 1>{});
+      kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{});
+    }
+    static_assert(PD == 4, "the unrolled ring above");
+    if (kb < k_end) kstep(std::integral_constant<int, 0>{});
+    if (kb + GK < k_end) kstep(std::integral_constant<int, 1>{});
+    if (kb + 2 * GK < k_end) kstep(std::integral_constant<int, 2>{});
+    if (kb + 3 * GK < k_end) kstep(std::integral_constant<int, 3>{});   // (fewer than PD * GK elements left can still be PD steps, the last one partial)
   };
-  // Steady state: PD steps per iteration with NO branch inside — hipcc's s_waitcnt insertion loses track of which loads have
-  // landed at every control-flow merge and then waits for (nearly) all of them before it reuses a ring register, which
-  // serialises the ring just like the vmcnt(0) above.  The remaining steps (up to PD, the last one partial) follow with their tests.
-  int kb = k_begin;
-  for (; kb + PD * GK <= k_end; kb += PD * GK) {
-    kstep(std::integral_constant<int, 0>{});
-    kstep(std::integral_constant<int, 1>{});
-    kstep(std::integral_constant<int, 2>{});
-    kstep(std::integral_constant<int, 3>{});
-  }
-  static_assert(PD == 4, "the unrolled ring above");
-  if (kb < k_end) kstep(std::integral_constant<int, 0>{});
-  if (kb + GK < k_end) kstep(std::integral_constant<int, 1>{});
-  if (kb + 2 * GK < k_end) kstep(std::integral_constant<int, 2>{});
-  if (kb + 3 * GK < k_end) kstep(std::integral_constant<int, 3>{});   // (fewer than PD * GK elements left can still be PD steps, the last one partial)
+  const bool fast = !CV && m0 + GT <= g.M && n0 + GT <= g.N && (k_end - k_begin) % GK == 0;   // uniform over the workgroup
+  if (fast) run(std::true_type{});
+  else run(std::false_type{});
 
   // acc[a][b][r] = C[m0 + wm + 16 a + 4 q + r][n0 + wn + 16 b + i].  The tile goes through LDS so that a wave-instruction
   // writes 64 consecutive columns of one row (256 contiguous bytes when scn = 1) instead of 16 columns of 4 rows: fp32
   // atomics run at their full rate only for whole 256-byte wave-instructions (MI355X_MICROARCH.md, atomics), and the split-K
   // weight gradients are made of them.
+  SG_STAMP(4);
   if (rs_on) {   // lanes i, i + 16, i + 32, i + 48 hold the four k-quarters of row wm + 16 a + i
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -597,9 +646,9 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       if (q == 0 && m < g.M) atomicAdd(g.rowsum + m, v);
     }
   }
-  constexpr int CS = GT + 1;
+  constexpr int CS = GT + 4;   // (16-byte rows for the vector path below; conflict-free for the accumulator writes either way)
   static_assert(GT * CS <= 2 * BUF, "the output tile reuses the operand tiles");
-  __syncthreads();
+  // (the last K step ended with a barrier: every fragment read and staging write of the operand buffers is done)
   float* Cs = smem;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -608,19 +657,35 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cs[(wm + 16 * a + 4 * q + r) * CS + wn + 16 * b + i] = acc[a][b][r];
   __syncthreads();
-  const int n = n0 + lane;
-  if (n < g.N) {
-    const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.f;
-    float* cn = C + (long)n * g.scn;
-    for (int rr = wave; rr < GT; rr += 4) {
-      const int m = m0 + rr;
-      if (m >= g.M) break;
-      float* c = cn + (long)m * g.scm;
-      const float v = g.alpha * Cs[rr * CS + lane] + bias;
-      if (ksplit > 1) atomicAdd(c, v);
-      else *c = g.accumulate ? *c + v : v;
+  // interior tile of a row-major output without split-K: 16 bytes per lane, 4 store instructions per thread instead of 16
+  const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GT <= g.M && n0 + GT <= g.N &&
+                       ((reinterpret_cast<uintptr_t>(C) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
+  if (vec_out) {
+    const int c4 = 4 * (t & 15);
+    const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (t >> 4) + 16 * it;
+      f32x4* c = reinterpret_cast<f32x4*>(C + (long)(m0 + rr) * g.scm + n0 + c4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
+      *c = g.accumulate ? *c + v : v;
+    }
+  } else {
+    const int n = n0 + lane;
+    if (n < g.N) {
+      const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.f;
+      float* cn = C + (long)n * g.scn;
+      for (int rr = wave; rr < GT; rr += 4) {
+        const int m = m0 + rr;
+        if (m >= g.M) break;
+        float* c = cn + (long)m * g.scm;
+        const float v = g.alpha * Cs[rr * CS + lane] + bias;
+        if (ksplit > 1) atomicAdd(c, v);
+        else *c = g.accumulate ? *c + v : v;
+      }
     }
   }
+  SG_STAMP(5);
 }
 
 __global__ __launch_bounds__(256) void unary_kernel(int kind, const float* x, long n, float* y) {

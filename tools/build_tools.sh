@@ -12,11 +12,12 @@ mkdir -p tools/bin
 S=tools/bin/stamped
 mkdir -p $S
 pids=""
-for f in convblock enclayer gemm; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_STAMPS -x hip -c $C/$f.hip -o $S/$f.o & pids="$pids $!"; done
+for f in convblock enclayer gemm train; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_STAMPS -x hip -c $C/$f.hip -o $S/$f.o & pids="$pids $!"; done
 for pid in $pids; do wait $pid; done   # (a bare `wait` hides a failed compile from `set -e`)
 P=$S
 $H -c tools/bench_conv.cpp -o tools/bin/bench_conv.o && hipcc --offload-arch=gfx950 tools/bin/bench_conv.o $P/convblock.o $P/enclayer.o -o tools/bin/bench_conv
 $H -c tools/bench_enc.cpp -o tools/bin/bench_enc.o && hipcc --offload-arch=gfx950 tools/bin/bench_enc.o $P/enclayer.o -o tools/bin/bench_enc
+$H -c tools/bench_sgemm.cpp -o tools/bin/bench_sgemm.o && hipcc --offload-arch=gfx950 tools/bin/bench_sgemm.o $P/train.o -o tools/bin/bench_sgemm
 $H -c tools/bench_text.cpp -o tools/bin/bench_text.o && hipcc --offload-arch=gfx950 tools/bin/bench_text.o $P/gemm.o -o tools/bin/bench_text
 for t in bench_l2 bench_copy bench_handoff bench_lat; do $H tools/$t.cpp -o tools/bin/$t; done
 echo "built: $(ls tools/bin | grep -v '\.o$' | tr '\n' ' ')"
