@@ -690,8 +690,9 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       for (int r = 0; r < 4; ++r) Cs[(wm + 16 * a + 4 * q + r) * CS + wn + 16 * b + i] = acc[a][b][r];
   __syncthreads();
   // interior tile of a row-major output without split-K: 16 bytes per lane, 4 store instructions per thread instead of 16
+  const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend: launch_sgemm)
   const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GT <= g.M && n0 + GT <= g.N &&
-                       ((reinterpret_cast<uintptr_t>(C) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
+                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
   if (vec_out) {
     const int c4 = 4 * (t & 15);
     const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     for (int it = 0; it < 4; ++it) {
       const int rr = (t >> 4) + 16 * it;
       f32x4* c = reinterpret_cast<f32x4*>(C + (long)(m0 + rr) * g.scm + n0 + c4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
+      if (Dd) v += *reinterpret_cast<const f32x4*>(Dd + (long)(m0 + rr) * g.scm + n0 + c4);
       *c = g.accumulate ? *c + v : v;
     }
   } else {
@@ -713,7 +715,8 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
         const int m = m0 + rr;
         if (m >= g.M) continue;
         float* c = cn + (long)m * g.scm;
-        const float v = g.alpha * Cs[rr * CS + lane] + bias;
+        float v = g.alpha * Cs[rr * CS + lane] + bias;
+        if (Dd) v += Dd[(long)n * g.scn + (long)m * g.scm];
         if (ksplit > 1) atomicAdd(c, v);
         else *c = g.accumulate ? *c + v : v;
       }
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(256) void film_bwd2_kernel(const float* d, const fl
 // each way, the intermediate (FiLM output / normalised rows) is recomputed in the backward instead of stored and re-read.
 // y = act ? SiLU(x gamma[b] + beta[b]) : x gamma[b] + beta[b];   4 channels per thread (C % 4 == 0)
 __global__ __launch_bounds__(256) void film_act_fwd_kernel(const float* x, const float* gam, const float* bet, long pstride, int L, int C, long n4,
-                                                            int act, float* y) {
+                                                            int act, const float* addend, float* y) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const long e = i * 4, r = e / C;
@@ -887,6 +890,7 @@ __global__ __launch_bounds__(256) void film_act_fwd_kernel(const float* x, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[k] = silu_f(a[k]);
   }
+  if (addend) a += *reinterpret_cast<const f32x4*>(addend + e);   // (a residual add riding on the pass)
   *reinterpret_cast<f32x4*>(y + e) = a;
 }
 // backward of the above: d' = act ? dy * SiLU'(x gamma + beta) : dy;  dx (+)= d' gamma;  dgamma[b][c] += sum_l d' x;  dbeta[b][c] += sum_l d'
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(256) void film_act_bwd_kernel(const float* d, const
 }
 // y = LayerNorm(x) gamma[b] + beta[b]  (eps 1e-6, no LN affine; one wave per row; mean / rstd kept for the backward)
 __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L,
-                                                           float* y, float* mean_out, float* rstd_out) {
+                                                           const float* addend, float* y, float* mean_out, float* rstd_out) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long r
   for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
   const float rstd = rsqrtf(v / C + 1e-6f);
-  for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c];
+  for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c] + (addend ? addend[row * C + c] : 0.f);
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 // backward: xn = (x - mean) rstd;  dn = dy gamma;  dx (+)= rstd (dn - mean(dn) - xn mean(dn xn));  dgamma[b][c] += sum_l dy xn;  dbeta += sum_l dy.
@@ -1059,7 +1063,7 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   int ksplit = 1;
   static const long sk_target = getenv("DHW_SGEMM_SPLIT_WGS") ? atol(getenv("DHW_SGEMM_SPLIT_WGS")) : 512;   // (two workgroups per CU: 7.6 vs 7.8 ms per update against 256)
   static const long sk_steps = getenv("DHW_SGEMM_SPLIT_STEPS") ? atol(getenv("DHW_SGEMM_SPLIT_STEPS")) : 8;
-  if (g.accumulate && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
+  if (g.accumulate && !g.addend && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
   if (ksplit < 1) ksplit = 1;
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;
@@ -1113,9 +1117,10 @@ hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, lo
   hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
   return hipGetLastError();
 }
-hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* y, hipStream_t st) {
+hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, const float* addend, float* y,
+                               hipStream_t st) {
   const long n4 = (long)B * L * C / 4;
-  hipLaunchKernelGGL(film_act_fwd_kernel, dim3(nb(n4)), dim3(256), 0, st, x, gam, bet, pstride, L, C, n4, act, y);
+  hipLaunchKernelGGL(film_act_fwd_kernel, dim3(nb(n4)), dim3(256), 0, st, x, gam, bet, pstride, L, C, n4, act, addend, y);
   return hipGetLastError();
 }
 hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
@@ -1123,9 +1128,9 @@ hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam,
   hipLaunchKernelGGL(film_act_bwd_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, bet, pstride, L, C, act, du, accumulate, dgam, dbet);
   return hipGetLastError();
 }
-hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, float* y, float* mean, float* rstd,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, y, mean, rstd);
+hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
+                              float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, mean, rstd);
   return hipGetLastError();
 }
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,

@@ -108,7 +108,7 @@ class Tape:
 
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
              nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False,
-             rowsum=None):
+             rowsum=None, addend=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
 
@@ -127,7 +127,7 @@ class Tape:
                           Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
-                          rowsum.data_ptr() if rowsum is not None else None)
+                          addend.data_ptr() if addend is not None else None, rowsum.data_ptr() if rowsum is not None else None)
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
@@ -147,16 +147,31 @@ class Tape:
         _tcheck(getattr(self.lib, fn)(*args, self.side_st if side else self.st))
         self.launches += 1
 
+    def _grad_to(self, v: "Var", dy: torch.Tensor):
+        """d v (+)= dy for an addend v of an op whose output gradient buffer dy is dead afterwards: v takes the buffer if it has
+        no gradient yet (later fan-in adds go into it), else one add."""
+        if v.leaf:
+            return
+        if v.g is None and not isinstance(v, _ViewVar):
+            v.g = dy
+            return
+        dv, acc = self.into(v)
+        self.call("dhw_op_add", dy.data_ptr(), None, dy.numel(), dv.data_ptr(), acc)
+
     # ---- differentiable ops ------------------------------------------------------------------------------------------
-    def linear(self, x: Var, W: Var, b: Var | None) -> Var:
-        """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]."""
+    def linear(self, x: Var, W: Var, b: Var | None, addend: Var | None = None) -> Var:
+        """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]; ``addend`` [R, N]: the residual added to the result
+        in the GEMM's output pass (y = x W^T + b + addend)."""
         R, K = x.d.shape
         N = W.d.shape[0]
+        if addend is not None and -(-R // 64) * -(-N // 64) < 64 and K >= 512:   # (split-K output: the add stays a pass of its own)
+            return self.add(self.linear(x, W, b), addend)
         # few output tiles and a long contraction (sigma_ffn's 2048 -> 32): zero the output and let the GEMM split K over
         # workgroups with atomics, instead of one workgroup walking all of K
         split = -(-R // 64) * -(-N // 64) < 64 and K >= 512
         y = Var(torch.zeros(R, N, device=self.dev) if split else self.new(R, N))
-        self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None, acc=split)
+        self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None, acc=split,
+                  addend=addend.d if addend is not None else None)
 
         def bwd():
             dy = y.g
@@ -167,10 +182,12 @@ class Tape:
             if WGRAD_SIDE:
                 self.fork(dy, x.d)
             self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, rowsum=db, side=WGRAD_SIDE)   # dW += dy^T x, db += column sums of dy
+            if addend is not None:
+                self._grad_to(addend, dy)
         self.record(y, bwd)
         return y
 
-    def conv3(self, x: Var, W: Var, b: Var, L: int) -> Var:
+    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None) -> Var:
         """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
         have any strides: TrainModel keeps the Conv1d weights as [tap][Cout][Cin] in memory (unit stride along Cin), which makes the
         weight the 16-byte-load operand of all three GEMMs; a torch-contiguous W works too (scalar loads, stride-3 stores)."""
@@ -181,11 +198,11 @@ class Tape:
         merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
         if merged:
             self.gemm(x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
-                      sbt=st, lr=L)
+                      sbt=st, lr=L, addend=addend.d if addend is not None else None)
         else:
             for t in range(3):
                 self.gemm(x.d, 0, Cin, 1, W.d, t * st, sci, sco, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
-                          a_shift=t - 1, lr=L)
+                          a_shift=t - 1, lr=L, addend=addend.d if addend is not None and t == 0 else None)
 
         def bwd():
             dy, dW, db = y.g, W.grad(), b.grad()
@@ -204,6 +221,8 @@ class Tape:
                     self.gemm(dy, 0, Cout, 1, W.d, t * st, sco, sci, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
                     self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t * gt, gco, gci, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L,
                               rowsum=db if t == 1 else None, side=WGRAD_SIDE)
+            if addend is not None:
+                self._grad_to(addend, dy)
         self.record(y, bwd)
         return y
 
@@ -272,7 +291,7 @@ class Tape:
         self.record(y, bwd)
         return y
 
-    def film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, act: bool = False) -> Var:
+    def film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, act: bool = False, addend: Var | None = None) -> Var:
         """``film`` with gamma / beta taken from columns [col, col + C) of a [B, TOT] table (dhw_op_film_table); ``act``: followed
         by SiLU in the same pass (the ConvBlock's ``SiLU(affine(conv(.)))``, cnn.py:70-80) — one launch each way instead of two,
         the FiLM output is recomputed in the backward instead of stored."""
@@ -280,17 +299,20 @@ class Tape:
         L, TOT = R // B, table.d.shape[1]
         y = Var(torch.empty_like(x.d))
         base = table.d.data_ptr()
-        self.call("dhw_op_film_act", x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act), y.d.data_ptr())
+        self.call("dhw_op_film_act", x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act),
+                  addend.d.data_ptr() if addend is not None else None, y.d.data_ptr())
 
         def bwd():
             dx, acc = self.into(x)
             gbase = table.grad().data_ptr()
             self.call("dhw_op_film_act_bwd", y.g.data_ptr(), x.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act),
                       dx.data_ptr(), acc, gbase + col_g * _F, gbase + col_b * _F)
+            if addend is not None:
+                self._grad_to(addend, y.g)
         self.record(y, bwd)
         return y
 
-    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int) -> Var:
+    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, addend: Var | None = None) -> Var:
         """LayerNorm followed by FiLM (every EncoderLayer / TextStyleEncoder pairs them: model.py:44-58, text_style.py:98-110) in one
         pass each way; the normalised rows are recomputed in the backward from the saved mean / rstd."""
         R, Cc = x.d.shape
@@ -298,13 +320,16 @@ class Tape:
         y = Var(torch.empty_like(x.d))
         mean, rstd = self.new(R), self.new(R)
         base = table.d.data_ptr()
-        self.call("dhw_op_ln_film", x.d.data_ptr(), B, L, Cc, base + col_g * _F, base + col_b * _F, TOT, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+        self.call("dhw_op_ln_film", x.d.data_ptr(), B, L, Cc, base + col_g * _F, base + col_b * _F, TOT,
+                  addend.d.data_ptr() if addend is not None else None, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
 
         def bwd():
             dx, acc = self.into(x)
             gbase = table.grad().data_ptr()
             self.call("dhw_op_ln_film_bwd", y.g.data_ptr(), x.d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), base + col_g * _F, TOT, B, L, Cc,
                       dx.data_ptr(), acc, gbase + col_g * _F, gbase + col_b * _F)
+            if addend is not None:
+                self._grad_to(addend, y.g)
         self.record(y, bwd)
         return y
 
@@ -490,12 +515,12 @@ class TrainModel:
             self.pe(Lt, d, 1.0)
 
     # ---- modules ---------------------------------------------------------------------------------------------------------
-    def _lin(self, t, x, name):
-        return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
+    def _lin(self, t, x, name, addend=None):
+        return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"), addend)
 
-    def _ffn(self, t, x, name):
-        """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear."""
-        return self._lin(t, t.silu(self._lin(t, t.silu(x), name + ".1")), name + ".3")
+    def _ffn(self, t, x, name, addend=None):
+        """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear (+ the residual that follows it, in the last GEMM)."""
+        return self._lin(t, t.silu(self._lin(t, t.silu(x), name + ".1")), name + ".3", addend)
 
     def _film_table(self, t, sigma, B):
         """gamma / beta of all AffineTransformLayers for this sigma: one launch forward, two backward (instead of 76 small
@@ -507,16 +532,16 @@ class TrainModel:
                                        sigma.grad().data_ptr()))
         self._film = table
 
-    def _affine(self, t, x, sigma, name, B, act=False):
-        return t.film_cols(x, self._film, *self.film_cols[name], B, act)
+    def _affine(self, t, x, sigma, name, B, act=False, addend=None):
+        return t.film_cols(x, self._film, *self.film_cols[name], B, act, addend)
 
-    def _ln_affine(self, t, x, sigma, name, B):
-        """affine(layernorm(x)) as one fused pass (LN statistics span at most 512 channels here)."""
-        return t.ln_film_cols(x, self._film, *self.film_cols[name], B)
+    def _ln_affine(self, t, x, sigma, name, B, addend=None):
+        """affine(layernorm(x)) (+ addend) as one fused pass (LN statistics span at most 512 channels here)."""
+        return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend)
 
-    def _mha(self, t, q, k, v, name, B, H, mask=None):
+    def _mha(self, t, q, k, v, name, B, H, mask=None, addend=None):
         o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
-        return self._lin(t, o, name + ".dense")
+        return self._lin(t, o, name + ".dense", addend)
 
     def _convblock(self, t, x, sigma, name, B, L):
         """cnn.py:64-87."""
@@ -524,8 +549,7 @@ class TrainModel:
         skip = conv(x, "conv_skip")
         h = self._affine(t, conv(t.silu(x), "conv1"), sigma, name + ".affine1", B, act=True)      # SiLU(affine1(.)) in one pass
         h = self._affine(t, conv(h, "conv2"), sigma, name + ".affine2", B, act=True)
-        h = self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B)
-        return t.add(h, skip)
+        return self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B, addend=skip)   # affine3(fc(h)) + conv_skip(x)
 
     def _drop(self, t, v, B):
         """EncoderLayer.drop (model.py:23): identity at rate 0; otherwise the next caller-supplied keep-mask (parity tests) or a
@@ -548,11 +572,15 @@ class TrainModel:
         text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
-        x2 = t.add(self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B), x)
-        x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)
-        x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
-        x3 = self._ln_affine(t, t.add(x2, self._drop(t, x3, B)), sigma, name + ".affine2", B)
-        x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn"), B), x3)
+        x2 = self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B, addend=x)        # the residual adds ride on the
+        x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)                                         # passes / GEMMs around them
+        if self.drop_rate == 0.0:
+            x3 = self._ln_affine(t, self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H, addend=x2), sigma, name + ".affine2", B)
+            x4 = self._ffn(t, x3, name + ".ffn", addend=x3)
+        else:       # (the dropout sits between the GEMM and the add)
+            x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
+            x3 = self._ln_affine(t, t.add(x2, self._drop(t, x3, B)), sigma, name + ".affine2", B)
+            x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn"), B), x3)
         return self._ln_affine(t, x4, sigma, name + ".affine3", B)
 
     def _text_style(self, t, ids, style, sigma, keep, B):
@@ -565,8 +593,7 @@ class TrainModel:
         stf = self._ln_affine(t, stf, sigma, n + ".affine1", B)
         tx = t.embedding(ids, self.p[n + ".emb.weight"])
         tx = self._ln_affine(t, tx, sigma, n + ".affine2", B)
-        m = self._mha(t, tx, stf, stf, n + ".mha", B, 8)
-        tx = self._ln_affine(t, t.add(tx, m), sigma, n + ".affine3", B)
+        tx = self._ln_affine(t, self._mha(t, tx, stf, stf, n + ".mha", B, 8, addend=tx), sigma, n + ".affine3", B)
         return self._ln_affine(t, self._ffn(t, tx, n + ".text_ffn"), sigma, n + ".affine4", B)
 
     # ---- forward / backward ----------------------------------------------------------------------------------------------
@@ -613,10 +640,11 @@ class TrainModel:
         x = self._lin(t, t.resample(0, h3), "att_dense")
         for i in range(self.num_layers):
             x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1)
-        skip = lambda v, n, Lr: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr)   # noqa: E731
-        x = self._convblock(t, t.add(t.resample(2, x), skip(h3, "skip_conv3", L // 4)), sigma_v, "dec3", B, L // 4)
-        x = self._convblock(t, t.add(t.resample(2, x), skip(h2, "skip_conv2", L // 2)), sigma_v, "dec2", B, L // 2)
-        x = self._convblock(t, t.add(t.resample(2, x), skip(h1, "skip_conv1", L)), sigma_v, "dec1", B, L)
+        # upsample(x) + skip_conv(h): the add rides on the skip convolution's output pass
+        skip = lambda v, n, Lr, up: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr, addend=up)   # noqa: E731
+        x = self._convblock(t, skip(h3, "skip_conv3", L // 4, t.resample(2, x)), sigma_v, "dec3", B, L // 4)
+        x = self._convblock(t, skip(h2, "skip_conv2", L // 2, t.resample(2, x)), sigma_v, "dec2", B, L // 2)
+        x = self._convblock(t, skip(h1, "skip_conv1", L, t.resample(2, x)), sigma_v, "dec1", B, L)
         self._score = self._lin(t, x, "output_dense")
         self._pen = t.sigmoid(self._lin(t, x, "pen_lifts_dense.0"))
         return self._score.d.view(B, L, 2), self._pen.d.view(B, L)

@@ -90,6 +90,7 @@ typedef struct {
   const float* bias; float alpha; int accumulate;
   int bf16;   /* 0: exact-f32 MFMA.  1: the operands (fp32 in memory) are rounded to bf16 on their way into LDS and contracted on
                  the bf16 MFMA with fp32 accumulation — mixed-precision training with fp32 master weights */
+  const float* addend;   /* NULL, or an array laid out as C: C = alpha A B + bias + addend — a residual add in the GEMM's output pass */
   float* rowsum;   /* NULL, or [M]: rowsum[m] += sum_k A(0,m,k) (batch z = 0 only) — the bias gradient of a Linear / Conv1d comes out
                       of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum) */
 } dhw_gemm_desc;
@@ -110,12 +111,14 @@ int dhw_op_film_bwd(const float* dy, const float* x, const float* gamma, long lo
 /* Fused element-wise chains (one HBM pass each way; the intermediate is recomputed in the backward):
  *   film_act : y = act ? SiLU(x gamma[b] + beta[b]) : x gamma[b] + beta[b]     (conditioning.py:23-26 [+ the SiLU that follows in cnn.py:70-80])
  *   ln_film  : y = LayerNorm(x) gamma[b] + beta[b]                             (model.py:25 + conditioning.py:23-26, as every EncoderLayer chains them)
+ * Both take an optional addend (same shape as y): y += addend, the residual add that follows them in ConvBlock / EncoderLayer; its gradient is dy.
  * gamma / beta: per-sample rows [B][pstride]; the backward ADDS into dgamma / dbeta (same layout) and writes or adds dx. */
-int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* y, void* hip_stream);
+int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, const float* addend /* or NULL */,
+                    float* y, void* hip_stream);
 int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* dx,
                         int accumulate, float* dgamma, float* dbeta, void* hip_stream);
-int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, float* y, float* mean, float* rstd,
-                   void* hip_stream);
+int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend /* or NULL */, float* y,
+                   float* mean, float* rstd, void* hip_stream);
 int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,
                        float* dx, int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* hip_stream);
