@@ -490,13 +490,33 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // step's base pointers are scalar (past the end of the slice: the first step again — valid memory, never contracted).  The
   // per-element selects, compares and 64-bit address adds of the general form are ~100 VALU instructions per step, and VALU
   // issue stalls the same SIMD's MFMA pipe: a step took 0.85-0.95 us against 0.43 us of MFMA work (tools/bench_sgemm stamps).
-  auto load = [&](float (&ra)[8], float (&rb)[8], unsigned& okbits, auto fastc) {
-    constexpr bool FAST = decltype(fastc)::value;
+  // MODE 2 / 3: the same for a Conv1d GEMM whose tile (2: forward / data gradient, row-shifted A) or K slice (3: weight gradient,
+  // row-shifted B) stays inside the operand: unmasked loads at the shifted addresses, one range test per load for the rows that
+  // cross a sample edge (zeroed at staging), nothing for the other operand.
+  auto load = [&](float (&ra)[8], float (&rb)[8], unsigned& okbits, auto modec) {
+    constexpr int MODE = decltype(modec)::value;
+    constexpr bool FAST = MODE != 0;
     if constexpr (FAST) {
       const int k0 = k_next < k_end ? k_next : k_begin;
       k_next += GK;
-      const float* Ab = A + (long)k0 * g.sak;
-      const float* Bb = B + (long)k0 * g.sbk;
+      const int tap = MODE >= 2 && g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
+      const int a_sh = MODE >= 2 ? g.a_shift + tap * g.a_tap_shift : 0;
+      const float* Ab = A + (long)a_sh * g.sam + (long)kb * g.sak;
+      const float* Bb = B + (MODE >= 2 ? tap * g.sbt : 0) + (long)(kb + b_sh) * g.sbk;
+      unsigned bits = 0xffffu;
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) bits &= ~(((unsigned)(mla[j] + a_sh) < lr_a ? 0u : 1u) << j);
+      }
+      if constexpr (MODE == 3) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          bits &= ~(((unsigned)(klb[j] + b_sh) < lr_b ? 0u : 1u) << (8 + j));
+          klb[j] += GK;
+          if (g.lr >= GK) klb[j] -= klb[j] >= g.lr ? g.lr : 0;
+          else klb[j] %= g.lr;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         if constexpr (AV) {
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
           rb[j] = Bb[vob[j]];
         }
       }
-      okbits = 0xffffu;
+      okbits = bits;
       return;
     }
     const int k0 = k_next;
@@ -557,11 +577,15 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
     okbits = bits;
   };
-  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits, int buf, auto fastc) {
-    constexpr bool FAST = decltype(fastc)::value;
+  auto stage = [&](const float (&ra)[8], const float (&rb)[8], unsigned bits, int buf, auto modec) {
+    constexpr int MODE = decltype(modec)::value;
     TS* As = reinterpret_cast<TS*>(smem) + buf * BUFE;
     TS* Bs = As + GT * TR;
-    auto z = [&](int bit, float v) { if constexpr (FAST) return v; else return (bits >> bit) & 1u ? v : 0.f; };
+    auto z = [&](int bit, float v) {   // (bit is a constant after unrolling: A loads 0..7, B loads 8..15)
+      if constexpr (MODE == 1) return v;
+      else if ((MODE == 2 && bit >= 8) || (MODE == 3 && bit < 8)) return v;
+      else return (bits >> bit) & 1u ? v : 0.f;
+    };
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       if constexpr (AKM) {
@@ -659,9 +683,26 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     if (kb + 2 * GK < k_end) kstep(std::integral_constant<int, 2>{});
     if (kb + 3 * GK < k_end) kstep(std::integral_constant<int, 3>{});   // (fewer than PD * GK elements left can still be PD steps, the last one partial)
   };
-  const bool fast = !CV && m0 + GT <= g.M && n0 + GT <= g.N && (k_end - k_begin) % GK == 0;   // uniform over the workgroup
-  if (fast) run(std::true_type{});
-  else run(std::false_type{});
+  // (uniform over the workgroup)
+  const bool interior = m0 + GT <= g.M && n0 + GT <= g.N && (k_end - k_begin) % GK == 0;
+  if constexpr (!CV) {
+    if (interior) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+  } else {
+    int mode = 0;
+    const bool ashift = g.a_shift != 0 || g.a_tap_shift != 0, bshift = g.b_shift != 0 || g.b_z_shift != 0;
+    if (interior && g.lr > 0) {
+      if (ashift && !bshift) {   // every shifted row of the tile is a row of A (those of a neighbouring sample are zeroed by their bit)
+        const int s0 = g.a_shift, s1 = g.a_shift + (g.taps - 1) * g.a_tap_shift;
+        if (m0 + min(s0, s1) >= 0 && m0 + GT - 1 + max(s0, s1) < g.M) mode = 2;
+      } else if (bshift && !ashift && g.taps == 1) {
+        if (k_begin + b_sh >= 0 && k_end - 1 + b_sh < g.K) mode = 3;
+      }
+    }
+    if (mode == 2) run(std::integral_constant<int, 2>{});
+    else if (mode == 3) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 0>{});
+  }
 
   // acc[a][b][r] = C[m0 + wm + 16 a + 4 q + r][n0 + wn + 16 b + i].  The tile goes through LDS so that a wave-instruction
   // writes 64 consecutive columns of one row (256 contiguous bytes when scn = 1) instead of 16 columns of 4 rows: fp32
