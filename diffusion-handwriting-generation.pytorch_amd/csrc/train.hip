@@ -497,21 +497,27 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     constexpr int MODE = decltype(modec)::value;
     constexpr bool FAST = MODE != 0;
     if constexpr (FAST) {
-      const int k0 = k_next < k_end ? k_next : k_begin;
+      const bool past = k_next >= k_end;      // (uniform) a request past the end of the slice: never contracted
+      const int k0 = past ? k_begin : k_next;
       k_next += GK;
       const int tap = MODE >= 2 && g.taps > 1 ? k0 / Kt : 0, kb = k0 - tap * Kt;
       const int a_sh = MODE >= 2 ? g.a_shift + tap * g.a_tap_shift : 0;
       const float* Ab = A + (long)a_sh * g.sam + (long)kb * g.sak;
       const float* Bb = B + (MODE >= 2 ? tap * g.sbt : 0) + (long)(kb + b_sh) * g.sbk;
+      // (a row that falls outside the operand is always a row that crosses a sample edge — M and K are whole samples — so the one
+      // range test also keeps the load inside the buffer: it is issued at the operand's base instead)
       unsigned bits = 0xffffu;
-      if constexpr (MODE == 2) {
+      bool ea[NA], eb[NB];
 #pragma unroll
-        for (int j = 0; j < NA; ++j) bits &= ~(((unsigned)(mla[j] + a_sh) < lr_a ? 0u : 1u) << j);
+      for (int j = 0; j < NA; ++j) {
+        ea[j] = MODE == 2 && (unsigned)(mla[j] + a_sh) >= lr_a;
+        if constexpr (MODE == 2) bits &= ~((ea[j] ? 1u : 0u) << j);
       }
-      if constexpr (MODE == 3) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          bits &= ~(((unsigned)(klb[j] + b_sh) < lr_b ? 0u : 1u) << (8 + j));
+      for (int j = 0; j < NB; ++j) {
+        eb[j] = MODE == 3 && (unsigned)(klb[j] + b_sh) >= lr_b;
+        if constexpr (MODE == 3) {
+          bits &= ~((eb[j] ? 1u : 0u) << (8 + j));
           klb[j] += GK;
           if (g.lr >= GK) klb[j] -= klb[j] >= g.lr ? g.lr : 0;
           else klb[j] %= g.lr;
@@ -519,20 +525,23 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       }
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
+        const float* src = MODE == 2 && ea[j] ? A : Ab + voa[j];
         if constexpr (AV) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + voa[j]);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
           ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
         } else {
-          ra[j] = Ab[voa[j]];
+          ra[j] = *src;
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
+        // (MODE 3 past the end: klb has moved on while the address went back to the first step — everything from the base)
+        const float* src = MODE == 3 && (eb[j] || past) ? B : Bb + vob[j];
         if constexpr (BV) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bb + vob[j]);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
           rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
         } else {
-          rb[j] = Bb[vob[j]];
+          rb[j] = *src;
         }
       }
       okbits = bits;
@@ -692,12 +701,8 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     int mode = 0;
     const bool ashift = g.a_shift != 0 || g.a_tap_shift != 0, bshift = g.b_shift != 0 || g.b_z_shift != 0;
     if (interior && g.lr > 0) {
-      if (ashift && !bshift) {   // every shifted row of the tile is a row of A (those of a neighbouring sample are zeroed by their bit)
-        const int s0 = g.a_shift, s1 = g.a_shift + (g.taps - 1) * g.a_tap_shift;
-        if (m0 + min(s0, s1) >= 0 && m0 + GT - 1 + max(s0, s1) < g.M) mode = 2;
-      } else if (bshift && !ashift && g.taps == 1) {
-        if (k_begin + b_sh >= 0 && k_end - 1 + b_sh < g.K) mode = 3;
-      }
+      if (ashift && !bshift && g.M % g.lr == 0) mode = 2;
+      else if (bshift && !ashift && g.taps == 1 && g.K % g.lr == 0) mode = 3;
     }
     if (mode == 2) run(std::integral_constant<int, 2>{});
     else if (mode == 3) run(std::integral_constant<int, 3>{});
