@@ -119,6 +119,38 @@ def test_elementwise_norm_and_resampling_ops():
         _close(mine, r)
 
 
+def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
+    """``addend`` of linear / conv3 (dhw_gemm_desc.addend), film_cols and ln_film_cols: y = op(x) + r, d r = d y, with fan-in on r
+    (model.py:44-58 and cnn.py:87 chain exactly these); sizes with edge tiles (scalar output path) and interior tiles (vector path)."""
+    g = torch.Generator().manual_seed(11)
+    for B, L, Cin, Cout in ((2, 24, 64, 96), (4, 64, 128, 128)):
+        R = B * L
+        x = torch.randn(R, Cin, generator=g, requires_grad=True)
+        r = torch.randn(R, Cout, generator=g, requires_grad=True)
+        W = torch.randn(Cout, Cin, generator=g, requires_grad=True)
+        W3 = torch.randn(Cout, Cout, 3, generator=g, requires_grad=True)
+        b = torch.randn(Cout, generator=g, requires_grad=True)
+        b3 = torch.randn(Cout, generator=g, requires_grad=True)
+        table = torch.randn(B, 4 * Cout, generator=g, requires_grad=True)     # gamma | beta for the FiLM, gamma | beta for LN + FiLM
+
+        def build(t, x, r, W, W3, b, b3, table):
+            h = t.linear(x, W, b, addend=r)                                    # x W^T + b + r
+            h = t.conv3(h, W3, b3, L, addend=r)                                # second consumer of r: its gradient is a fan-in
+            h = t.film_cols(h, table, 0, Cout, B, act=True, addend=r)
+            return t.ln_film_cols(h, table, 2 * Cout, 3 * Cout, B, addend=h)
+
+        y, vs, dy = _run(build, (x, r, W, W3, b, b3, table))
+        h = F.linear(x, W, b) + r
+        h = F.conv1d(h.view(B, L, Cout).transpose(1, 2), W3, b3, padding="same").transpose(1, 2).reshape(R, Cout) + r
+        ga, be, ga2, be2 = (table[:, i * Cout:(i + 1) * Cout] for i in range(4))
+        h = F.silu(h.view(B, L, Cout) * ga[:, None] + be[:, None]).reshape(R, Cout) + r
+        ref = (F.layer_norm(h, (Cout,), eps=1e-6).view(B, L, Cout) * ga2[:, None] + be2[:, None]).reshape(R, Cout) + h
+        ref.backward(dy)
+        _close(y.d, ref)
+        for v, t_ref in zip(vs, (x, r, W, W3, b, b3, table)):
+            _close(v.g, t_ref.grad)
+
+
 def test_embedding_gather_and_scatter():
     g = torch.Generator().manual_seed(4)
     table = torch.randn(73, 48, generator=g, requires_grad=True)
