@@ -4,6 +4,7 @@
 //   0 loads then VALU        1 VALU then loads        2 interleaved (1 load per NV/NL VALU)
 //   3 waves 0-3 loads first, waves 4-7 VALU first (partners on a SIMD in opposite phases)
 //   4 loads only             5 VALU only
+//   6 as 3, VALU phases at s_setprio 3      7 as 0 (same order in every wave), VALU phases at s_setprio 3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,11 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ buf, float* s
     } else if constexpr (ORDER == 3) {
       if (wave < 4) { loads<NL>(p, v); __builtin_amdgcn_sched_barrier(0); valu<NV>(a); }
       else { valu<NV>(a); __builtin_amdgcn_sched_barrier(0); loads<NL>(p, v); }
+    } else if constexpr (ORDER == 6) {
+      if (wave < 4) { loads<NL>(p, v); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); valu<NV>(a); __builtin_amdgcn_s_setprio(0); }
+      else { __builtin_amdgcn_s_setprio(3); valu<NV>(a); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); loads<NL>(p, v); }
+    } else if constexpr (ORDER == 7) {
+      loads<NL>(p, v); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); valu<NV>(a); __builtin_amdgcn_s_setprio(0);
     } else if constexpr (ORDER == 4) { loads<NL>(p, v); }
     else { valu<NV>(a); for (int i = 0; i < NL; ++i) v[i] = make_uint4(0, 0, 0, 0); }
 #pragma unroll
@@ -66,7 +72,8 @@ int main() {
   uint4* buf; float* sink; unsigned long long* t;
   CK(hipMalloc(&buf, 4 << 20)); CK(hipMemset(buf, 1, 4 << 20)); CK(hipMalloc(&sink, 4096)); CK(hipMalloc(&t, 256 * 8));
 #define ALL(NL, NV) run<NL, NV, 4>(buf, sink, t, "loads only"); run<NL, NV, 5>(buf, sink, t, "VALU only"); run<NL, NV, 0>(buf, sink, t, "loads then VALU"); \
-  run<NL, NV, 1>(buf, sink, t, "VALU then loads"); run<NL, NV, 2>(buf, sink, t, "interleaved"); run<NL, NV, 3>(buf, sink, t, "partners in opposite order");
+  run<NL, NV, 1>(buf, sink, t, "VALU then loads"); run<NL, NV, 2>(buf, sink, t, "interleaved"); run<NL, NV, 3>(buf, sink, t, "partners in opposite order"); \
+  run<NL, NV, 6>(buf, sink, t, "opposite order + VALU prio 3"); run<NL, NV, 7>(buf, sink, t, "loads then VALU at prio 3");
   ALL(12, 192) ALL(12, 384) ALL(24, 384) ALL(24, 768) ALL(6, 192)
   return 0;
 }
