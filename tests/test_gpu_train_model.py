@@ -51,7 +51,9 @@ def test_linear_and_conv3_in_all_three_directions():
     # (40, 72): not multiples of 16 / 32 — the GEMM's edge masking, one launch per tap; (64, 96): the three taps merged into
     # one contraction (dhw_gemm_desc.taps) and, for the weight gradient, into the batch index
     # (32, 32) at L = 4 / 2 / 1: samples shorter than a K step (the deepest level of an L = 8 .. 32 batch)
-    for B, L, Cin, Cout in ((3, 20, 40, 72), (2, 24, 64, 96), (5, 4, 32, 32), (3, 2, 32, 64), (4, 1, 64, 32)):
+    # (5, 96, 64, 128), (6, 160, 128, 64): whole 64-row tiles and whole K steps — the unmasked K loops of the Conv1d forms, whose
+    # only per-element test is the sample-edge one (first / last tile and K slice included), next to a ragged last tile
+    for B, L, Cin, Cout in ((3, 20, 40, 72), (2, 24, 64, 96), (5, 4, 32, 32), (3, 2, 32, 64), (4, 1, 64, 32), (5, 96, 64, 128), (6, 160, 128, 64)):
         x = torch.randn(B * L, Cin, generator=g, requires_grad=True)
         W = torch.randn(Cout, Cin, 3, generator=g, requires_grad=True)
         b = torch.randn(Cout, generator=g, requires_grad=True)
