@@ -1110,7 +1110,8 @@ void schedule_host(int T, std::vector<float>& beta, std::vector<float>& alpha) {
   const int half = T / 2;
   double a = 1.0;   // torch's CPU cumprod accumulates float inputs in double (acc_type) and rounds each output
   for (int i = 0; i < T; ++i) {
-    const float x = i < half ? fmaf(step, (float)i, lo) : fmaf(-step, (float)(T - 1 - i), hi);
+    // (a one-point linspace is its START: torch.linspace(a, b, 1) = [a]; the symmetric form alone gave the end point for T = 1)
+    const float x = T == 1 ? lo : i < half ? fmaf(step, (float)i, lo) : fmaf(-step, (float)(T - 1 - i), hi);
     beta[i] = 0.02f + expf(x);
     a = a * (double)(1.0f - beta[i]);
     alpha[i] = (float)a;

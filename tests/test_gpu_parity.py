@@ -378,6 +378,14 @@ def test_shape_sweep_bf16_tracks_the_fp32_path(B, L, Lt, T):
     scale = ref[..., :2].abs().max().item()
     assert (got[..., :2] - ref[..., :2]).abs().max().item() < 0.03 * scale      # bf16 weights / activations, T <= 2 steps
     assert (got[..., 2] - ref[..., 2]).abs().max().item() < 0.05
+    # ... and both against the CPU oracle on the first and last prompt of the batch, so the variants these shapes select are
+    # pinned by the oracle directly, not only through the library's own fp32 path
+    for b in sorted({0, B - 1}):
+        want, _ = ref_cpu.sample(_sd(2), tx[b:b + 1].cpu(), sv[b:b + 1].cpu(), L, nz[:, b:b + 1].cpu(), T=T)
+        wscale = want[..., :2].abs().max().item()
+        assert (ref[b:b + 1] - want).abs().max().item() < 1e-3 * max(1.0, wscale), b
+        assert (got[b:b + 1, :, :2] - want[..., :2]).abs().max().item() < 0.03 * wscale, b
+        assert (got[b:b + 1, :, 2] - want[..., 2]).abs().max().item() < 0.05, b
 
 
 def test_full_size_batch_matches_the_oracle_on_sampled_prompts():

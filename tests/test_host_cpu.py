@@ -3,6 +3,7 @@ declare, the schedule is pinned to the reference's, the state_dict inventory and
 reference, and the product path fails loudly (never falls back) when no HIP device is present."""
 import ctypes as C
 import json
+import math
 import os
 import re
 
@@ -54,6 +55,14 @@ def test_schedule_generalises_in_T():
     assert abs(b1000[0] - b60[0]) < 1e-7 and abs(b1000[-1] - b60[-1]) < 1e-6
     assert np.all(np.diff(b1000) > 0) and np.all(np.diff(a1000) < 0) and np.isfinite(a1000).all()
     assert _lib.lib().dhw_schedule(0, None, None) < 0
+    # every small schedule length against the reference's formula evaluated by torch (utils/nn.py:19-39, inference.py:81) — T = 1
+    # included: a one-point torch.linspace is its start, which the symmetric two-sided evaluation alone got wrong until round 3
+    for T in (1, 2, 3, 4, 5, 8, 16, 61):
+        beta = 0.02 + torch.exp(torch.linspace(math.log(1e-5), math.log(0.4), T))
+        alpha = torch.cumprod(1 - beta, dim=0)
+        b, a = _lib.schedule(T)
+        assert np.allclose(b, beta.numpy(), rtol=3e-7, atol=0), T
+        assert np.allclose(a, alpha.numpy(), rtol=1e-6, atol=0), T
 
 
 @pytest.mark.parametrize("nl", [2, 4])
