@@ -565,10 +565,10 @@ class TrainModel:
         return t.dropout(v, keep, self.drop_rate)
 
     def _encoder(self, t, x, text, sigma, mask, name, B, H, pos_factor):
-        """EncoderLayer.forward (model.py:36-58)."""
+        """EncoderLayer.forward (model.py:36-58); ``text`` is SiLU(text features) already."""
         d = x.d.shape[1]
         Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
-        tx = self._ln_affine(t, self._lin(t, t.silu(text), name + ".text_dense"), sigma, name + ".affine0", B)
+        tx = self._ln_affine(t, self._lin(t, text, name + ".text_dense"), sigma, name + ".affine0", B)   # text: SiLU(text features), shared
         text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
@@ -630,7 +630,8 @@ class TrainModel:
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
         self._film_table(t, sigma_v, B)
-        txt = self._text_style(t, ids, sty, sigma_v, keep, B)                          # [B*Lt, 2 c2]
+        txt = t.silu(self._text_style(t, ids, sty, sigma_v, keep, B))                  # SiLU([B*Lt, 2 c2]): every EncoderLayer's text_dense starts
+                                                                                       # with it (model.py:38) — once, not once per layer
         x = self._lin(t, x_in, "input_dense")
         h1 = self._convblock(t, x, sigma_v, "enc1", B, L)
         h2 = self._convblock(t, t.resample(0, h1), sigma_v, "enc2", B, L // 2)
