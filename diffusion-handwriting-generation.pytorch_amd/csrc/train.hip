@@ -412,8 +412,13 @@ DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
 #else
 #define SG_STAMP(slot) do { } while (0)
 #endif
-template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV>
+// GM: rows of the output tile, 64 or 32 (columns: always 64).  32-row tiles are for GEMMs whose 64-row tiling would leave CUs
+// idle (1 600 - 1 920 rows x 384 columns = 150 - 180 workgroups at the attention level): twice the workgroups, half the K-loop
+// work each.
+template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV, int GM = GT>
 __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
+  static_assert(GM == 64 || GM == 32, "row tile");
+  constexpr int MA = GM / 32;   // 16-row MFMA tiles per wave along M
   SG_STAMP(0);
   constexpr int TR = tile_row<TS>;
   // two buffers of operand tiles (TS) — step s is contracted out of one while step s + 1 is staged into the other — then the
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   constexpr int BUFE = BUF * (int)(sizeof(float) / sizeof(TS));          // the same in elements of TS
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
   // grid: x = column tile, y = row tile, z = batch index * ksplit + K slice (each division only where its divisor is not 1)
-  const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT;
+  const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GM;
   int ks = 0, z = blockIdx.z, zo = z, zi = 0;
   if (ksplit > 1) { ks = z % ksplit; z /= ksplit; zo = z; }
   if (g.nzi > 1) { zo = z / g.nzi; zi = z - zo * g.nzi; }
@@ -452,15 +457,16 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // is a per-thread 32-bit constant, everything that changes from step to step (k position, tap, row shift) is uniform and
   // goes into the scalar base pointer; the per-step vector work is the validity compares.
   constexpr int PD = 4;
-  constexpr int NA = AV ? 2 : 8, NB = BV ? 2 : 8;      // loads per thread and step
+  constexpr int NA = (AV ? 2 : 8) * GM / GT, NB = BV ? 2 : 8;      // loads per thread and step (A: half of them for a 32-row tile)
   float rar[PD][8], rbr[PD][8];
   const int Kt = CV ? g.K / g.taps : g.K;       // taps > 1: Kt is a multiple of GK, so a K step lies inside one tap
   const int b_sh = CV ? g.b_shift + zi * g.b_z_shift : 0;
   const unsigned lr_a = CV && g.lr > 0 ? (unsigned)g.lr : 0x7fffffffu;     // no row shift: every row "in range"
   const unsigned lr_b = CV && b_sh != 0 ? (unsigned)g.lr : 0x7fffffffu;
   // local (tile) coordinates of load j: (am, ak) / (bn, bk); for a vector load the first of its 4 elements
-  auto a_m = [&](int j) { return AV ? (AM ? 4 * (t & 15) : (t >> 3) + 32 * j) : (AM ? (t & 63) : (t >> 5) + 8 * j); };
-  auto a_k = [&](int j) { return AV ? (AM ? (t >> 4) + 16 * j : 4 * (t & 7)) : (AM ? (t >> 6) + 4 * j : (t & 31)); };
+  // (GM = 32 with m along the lanes: 32 m per k row, so 8 / 32 lanes per row and 32 / 8 k rows per pass)
+  auto a_m = [&](int j) { return AV ? (AM ? 4 * (t & (GM / 4 - 1)) : (t >> 3) + 32 * j) : (AM ? (t & (GM - 1)) : (t >> 5) + 8 * j); };
+  auto a_k = [&](int j) { return AV ? (AM ? (GM == 64 ? (t >> 4) + 16 * j : (t >> 3)) : 4 * (t & 7)) : (AM ? (GM == 64 ? (t >> 6) + 4 * j : (t >> 5) + 8 * j) : (t & 31)); };
   auto b_n = [&](int j) { return BV ? (BK ? (t >> 3) + 32 * j : 4 * (t & 15)) : (BK ? (t >> 5) + 8 * j : (t & 63)); };
   auto b_k = [&](int j) { return BV ? (BK ? 4 * (t & 7) : (t >> 4) + 16 * j) : (BK ? (t & 31) : (t >> 6) + 4 * j); };
   unsigned voa[NA], vob[NB];
@@ -627,18 +633,18 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[MA][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = (wave >> 1) * (GM / 2), wn = (wave & 1) * 32;
 
   // bias gradient riding on the weight-gradient GEMM (g.rowsum): the waves that hold the A fragments of the first column tile
   // of batch 0 also add them up — 16 additions per lane and step instead of a second pass over dy (colsum_kernel: one launch
   // per Linear / Conv1d, 8.7 % of the update)
   const bool rs_on = g.rowsum != nullptr && n0 == 0 && z == 0 && wn == 0;   // (wave-uniform)
-  float rs[2] = {0.f, 0.f};
+  float rs[MA] = {};
   // Step s (ring slot p = s mod PD, LDS buffer p & 1): request step s + PD, read this step's fragments, and stage step
   // s + 1 into the other buffer between the two halves of the MFMA work — the matrix pipe runs while the wave does the
   // staging's selects and LDS writes; ONE barrier per step (everybody's reads of this buffer and writes of the next are done).
@@ -657,22 +663,27 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       const TS* Ac = reinterpret_cast<const TS*>(smem) + (p & 1) * BUFE;
       const TS* Bc = Ac + GT * TR;
       load(rar[p], rbr[p], okm[p], fastc);   // slot p was staged one step ago: it takes step s + PD (past k_end: clamped, all-zero)
-      Frag<TS> fa[2], fb[2];
+      Frag<TS> fa[MA], fb[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        if constexpr (AKM) fa[a] = ld_frag_k<TS>(reinterpret_cast<const float*>(Ac) + 8 * q * TRK + wm + 16 * a + i, TRK);
-        else fa[a] = ld_frag(Ac + (wm + 16 * a + i) * TR + 8 * q);
+        if (a < MA) {
+          if constexpr (AKM) fa[a % MA] = ld_frag_k<TS>(reinterpret_cast<const float*>(Ac) + 8 * q * TRK + wm + 16 * a + i, TRK);
+          else fa[a % MA] = ld_frag(Ac + (wm + 16 * a + i) * TR + 8 * q);
+        }
         if constexpr (BKM) fb[a] = ld_frag_k<TS>(reinterpret_cast<const float*>(Bc) + 8 * q * TRK + wn + 16 * a + i, TRK);
         else fb[a] = ld_frag(Bc + (wn + 16 * a + i) * TR + 8 * q);
       }
       mma32(acc[0][0], fa[0], fb[0]);
+      if constexpr (MA == 1) stage(rar[pn], rbr[pn], okm[pn], pn & 1, fastc);
       mma32(acc[0][1], fa[0], fb[1]);
-      stage(rar[pn], rbr[pn], okm[pn], pn & 1, fastc);
-      mma32(acc[1][0], fa[1], fb[0]);
-      mma32(acc[1][1], fa[1], fb[1]);
+      if constexpr (MA == 2) {
+        stage(rar[pn], rbr[pn], okm[pn], pn & 1, fastc);
+        mma32(acc[1][0], fa[1], fb[0]);
+        mma32(acc[1][1], fa[1], fb[1]);
+      }
       if (rs_on) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) rs[a] += frag_sum(fa[a]);
+        for (int a = 0; a < MA; ++a) rs[a] += frag_sum(fa[a]);
       }
       __syncthreads();
     };
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     if (kb + 3 * GK < k_end) kstep(std::integral_constant<int, 3>{});   // (fewer than PD * GK elements left can still be PD steps, the last one partial)
   };
   // (uniform over the workgroup)
-  const bool interior = m0 + GT <= g.M && n0 + GT <= g.N && (k_end - k_begin) % GK == 0;
+  const bool interior = m0 + GM <= g.M && n0 + GT <= g.N && (k_end - k_begin) % GK == 0;
   if constexpr (!CV) {
     if (interior) run(std::integral_constant<int, 1>{});
     else run(std::integral_constant<int, 0>{});
@@ -716,7 +727,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   SG_STAMP(4);
   if (rs_on) {   // lanes i, i + 16, i + 32, i + 48 hold the four k-quarters of row wm + 16 a + i
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < MA; ++a) {
       float v = rs[a];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
@@ -729,7 +740,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // (the last K step ended with a barrier: every fragment read and staging write of the operand buffers is done)
   float* Cs = smem;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -737,13 +748,13 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   __syncthreads();
   // interior tile of a row-major output without split-K: 16 bytes per lane, 4 store instructions per thread instead of 16
   const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend: launch_sgemm)
-  const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GT <= g.M && n0 + GT <= g.N &&
+  const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GM <= g.M && n0 + GT <= g.N &&
                        ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
   if (vec_out) {
     const int c4 = 4 * (t & 15);
     const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < GM / 16; ++it) {
       const int rr = (t >> 4) + 16 * it;
       f32x4* c = reinterpret_cast<f32x4*>(C + (long)(m0 + rr) * g.scm + n0 + c4);
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
@@ -756,8 +767,8 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       const float bias = (g.bias && ks == 0) ? g.bias[n] : 0.f;
       float* cn = C + (long)n * g.scn;
       const int rot = ks * 20;   // K slices of one tile start at different rows: their atomics meet on different cache lines
-      for (int r0 = wave; r0 < GT; r0 += 4) {
-        const int rr = (r0 + rot) & (GT - 1);
+      for (int r0 = wave; r0 < GM; r0 += 4) {
+        const int rr = (r0 + rot) & (GM - 1);
         const int m = m0 + rr;
         if (m >= g.M) continue;
         float* c = cn + (long)m * g.scm;
@@ -1116,8 +1127,7 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   if (ksplit < 1) ksplit = 1;
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;
-  if (tiles_m > 65535 || (long)g.nzo * g.nzi * ksplit > 65535) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)(g.nzo * g.nzi * ksplit)), block(256);
+  if (tiles_m > 32767 || (long)g.nzo * g.nzi * ksplit > 65535) return hipErrorInvalidValue;
   // lanes run along the index whose stride is the smaller one; 16-byte loads where that stride is 1 and everything is aligned
   const bool am = std::llabs(g.sam) < std::llabs(g.sak), bk = std::llabs(g.sbk) < std::llabs(g.sbn);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -1137,6 +1147,17 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   static const KFn variants[64] = {DHW_SG16(float, false), DHW_SG16(bf16_t, false), DHW_SG16(float, true), DHW_SG16(bf16_t, true)};
 #undef DHW_SG16
 #undef DHW_SG4
+  // 32-row tiles where the 64-row tiling would leave CUs idle (fp32, 16-byte-load forms, no split-K): DHW_SGEMM_GM32=0 to compare
+  static const bool gm32_on = !(getenv("DHW_SGEMM_GM32") && atoi(getenv("DHW_SGEMM_GM32")) == 0);
+  const bool gm32 = gm32_on && av && bv && !g.bf16 && ksplit == 1 && wgs < 224 && g.M > 32;
+  const dim3 grid((unsigned)tiles_n, (unsigned)(gm32 ? (g.M + 31) / 32 : tiles_m), (unsigned)(g.nzo * g.nzi * ksplit)), block(256);
+  if (gm32) {
+#define DHW_SG32(AM_, BK_) sgemm_tiled_kernel<AM_, BK_, true, true, float, false, 32>, sgemm_tiled_kernel<AM_, BK_, true, true, float, true, 32>
+    static const KFn v32[8] = {DHW_SG32(false, false), DHW_SG32(false, true), DHW_SG32(true, false), DHW_SG32(true, true)};
+#undef DHW_SG32
+    hipLaunchKernelGGL(v32[am * 4 + bk * 2 + (cv ? 1 : 0)], grid, block, 0, st, g, ksplit, kslice);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(variants[(cv ? 32 : 0) + (g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, ksplit, kslice);
   return hipGetLastError();
 }
