@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-GEMM timing of one training update (configs[4] per-GPU shard: batch 32, L=480, Lt=50, fp32), eager launches with a pair
+"""Per-GEMM shapes and (host-bound: eager ctypes launches take longer than the kernels, use gemm_time.py or tools/bench_sgemm for
+kernel times) timing of one training update (configs[4] per-GPU shard: batch 32, L=480, Lt=50, fp32), eager launches with a pair
 of events around each dhw_op_gemm: which shapes the 73 % of the update spent in GEMMs go to.  Diagnostic, GPU only."""
 import collections
 import json
