@@ -1010,8 +1010,9 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   const int nl = d.num_layers;
   bool a3 = false, a5 = false;
   // enc2 / enc4 can continue into enc3.a / enc5.a the same way (bit 0 / bit 1), but the ConvBlock's row tiling (62 / 46 rows)
-  // is a worse fit for the layer than its own: measured 23.22 ms (off) / 23.21 (enc3) / 23.40 (enc5, both) -> off by default
-  static const int conv_chain = getenv("DHW_CHAIN_CONV") ? atoi(getenv("DHW_CHAIN_CONV")) : 0;
+  // is a worse fit for the layer than its own: r1 measured 23.22 ms (off) / 23.21 (enc3) / 23.40 (enc5, both); r3, after the kernels
+  // changed: 19.54 (off) / 19.40 (enc3: bit 0) / 19.62 (enc5: bit 1) / 19.45 (both), three alternating runs each -> enc3 only
+  static const int conv_chain = getenv("DHW_CHAIN_CONV") ? atoi(getenv("DHW_CHAIN_CONV")) : 1;
   {
     EncChain ch{};
     if (chain_ok && (conv_chain & 1)) { ch.mode = 1; ch.a = enc_params(c, "enc3", h->el[0], nullptr, L / 2, h->lpadX[0], text, nullptr); }

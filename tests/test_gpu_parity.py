@@ -296,6 +296,7 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     outs = {}
     for name, env in (("default", {}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
                       ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("no_chain", {"DHW_CHAIN": "0"}), ("conv_chain", {"DHW_CHAIN_CONV": "3"}),
+                      ("no_conv_chain", {"DHW_CHAIN_CONV": "0"}),
                       ("enc_bm64", {"DHW_ENC_BM": "64"}), ("enc_bm32", {"DHW_ENC_BM": "32"}), ("conv_bm64", {"DHW_CONV_BM": "64"}),
                       ("f32_enc_per_gemm", {"DHW_FUSE_F32": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
@@ -307,7 +308,8 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     assert (outs["default"] - outs["no_fused_heads"]).abs().max().item() < tol
     assert (outs["default"] - outs["no_fused_up"]).abs().max().item() < tol   # (bf16 only: fp32 keeps the separate GEMM)
     assert (outs["default"] - outs["no_chain"]).abs().max().item() < tol      # (bf16 only)
-    assert (outs["default"] - outs["conv_chain"]).abs().max().item() < tol    # (bf16 only; off by default)
+    assert (outs["default"] - outs["conv_chain"]).abs().max().item() < tol    # (bf16 only; the default is enc2 -> enc3.a alone)
+    assert (outs["default"] - outs["no_conv_chain"]).abs().max().item() < tol
     # row-tile sizes the launcher would pick for other batch sizes: per-row arithmetic does not depend on the tile
     # fp32: the fused EncoderLayer kernels against one launch per GEMM + stand-alone attention (bf16: switch has no effect)
     assert (outs["default"] - outs["f32_enc_per_gemm"]).abs().max().item() < tol
