@@ -228,6 +228,7 @@ struct OpGemm {
   float* C; long scm, scn, sczo, sczi;
   int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate, bf16;
+  float* act_out;        // or null: SiLU of the value written to C, same layout (the activation that follows a Linear / Conv1d; not with accumulate / split-K)
   const float* addend;   // or null: C = alpha A B + bias + addend (C's layout; a residual add in the output pass; no split-K then)
   float* rowsum;   // or null: rowsum[m] += sum_k A(0,m,k) (batch z = 0) — a Linear / Conv1d bias gradient out of its weight-gradient GEMM
   unsigned long long* stamps;   // diagnostics only (tools/bench_sgemm.cpp, -DDHW_STAMPS builds): s_memrealtime of one workgroup's phases, or null
@@ -250,7 +251,7 @@ hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* be
 hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
                                int accumulate, float* dgam, float* dbet, hipStream_t st);
 hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
-                              float* mean, float* rstd, hipStream_t st);
+                              float* act_out, float* mean, float* rstd, hipStream_t st);
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,
                               float* dx, int accumulate, float* dgam, float* dbet, hipStream_t st);
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st);

@@ -269,7 +269,7 @@ int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
   g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.sbt = d->sbt; g.b_shift = d->b_shift; g.b_z_shift = d->b_z_shift;
   g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
   g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr; g.taps = d->taps;
-  g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.stamps = nullptr;
+  g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.act_out = d->act_out; g.stamps = nullptr;
   THIP(launch_sgemm(g, (hipStream_t)hip_stream));
   return 0;
 }
@@ -316,10 +316,10 @@ int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, con
   THIP(launch_film_act_bwd(dy, x, gamma, beta, pstride, B, L, C, act, dx, accumulate, dgamma, dbeta, (hipStream_t)st));
   return 0;
 }
-int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend, float* y, float* mean,
-                   float* rstd, void* st) {
+int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend, float* y, float* act_out,
+                   float* mean, float* rstd, void* st) {
   OPCHECK(x && gamma && beta && y && mean && rstd && B > 0 && L > 0 && C > 0, "dhw_op_ln_film");
-  THIP(launch_ln_film_fwd(x, (long)B * L, C, gamma, beta, pstride, L, addend, y, mean, rstd, (hipStream_t)st));
+  THIP(launch_ln_film_fwd(x, (long)B * L, C, gamma, beta, pstride, L, addend, y, act_out, mean, rstd, (hipStream_t)st));
   return 0;
 }
 int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,

@@ -747,9 +747,10 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       for (int r = 0; r < 4; ++r) Cs[(wm + 16 * a + 4 * q + r) * CS + wn + 16 * b + i] = acc[a][b][r];
   __syncthreads();
   // interior tile of a row-major output without split-K: 16 bytes per lane, 4 store instructions per thread instead of 16
-  const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend: launch_sgemm)
+  const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend / act_out: launch_sgemm)
+  float* Ao = g.act_out ? g.act_out + zo * g.sczo + zi * g.sczi : nullptr;
   const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GM <= g.M && n0 + GT <= g.N &&
-                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
+                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | reinterpret_cast<uintptr_t>(Ao) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
   if (vec_out) {
     const int c4 = 4 * (t & 15);
     const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
@@ -760,6 +761,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
       if (Dd) v += *reinterpret_cast<const f32x4*>(Dd + (long)(m0 + rr) * g.scm + n0 + c4);
       *c = g.accumulate ? *c + v : v;
+      if (Ao) *reinterpret_cast<f32x4*>(Ao + (long)(m0 + rr) * g.scm + n0 + c4) = (f32x4){silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
     }
   } else {
     const int n = n0 + lane;
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
         if (Dd) v += Dd[(long)n * g.scn + (long)m * g.scm];
         if (ksplit > 1) atomicAdd(c, v);
         else *c = g.accumulate ? *c + v : v;
+        if (Ao) Ao[(long)n * g.scn + (long)m * g.scm] = silu_f(v);
       }
     }
   }
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(256) void film_act_bwd_kernel(const float* d, const
 }
 // y = LayerNorm(x) gamma[b] + beta[b]  (eps 1e-6, no LN affine; one wave per row; mean / rstd kept for the backward)
 __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L,
-                                                           const float* addend, float* y, float* mean_out, float* rstd_out) {
+                                                           const float* addend, float* y, float* act_out, float* mean_out, float* rstd_out) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -995,7 +998,11 @@ __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long r
   for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
   const float rstd = rsqrtf(v / C + 1e-6f);
-  for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c] + (addend ? addend[row * C + c] : 0.f);
+  for (int c = lane; c < C; c += 64) {
+    const float v = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c] + (addend ? addend[row * C + c] : 0.f);
+    y[row * C + c] = v;
+    if (act_out) act_out[row * C + c] = silu_f(v);   // (the SiLU an ff_network opens with, utils/nn.py:145)
+  }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 // backward: xn = (x - mean) rstd;  dn = dy gamma;  dx (+)= rstd (dn - mean(dn) - xn mean(dn xn));  dgamma[b][c] += sum_l dy xn;  dbeta += sum_l dy.
@@ -1123,6 +1130,7 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   int ksplit = 1;
   static const long sk_target = getenv("DHW_SGEMM_SPLIT_WGS") ? atol(getenv("DHW_SGEMM_SPLIT_WGS")) : 512;   // (two workgroups per CU: 7.6 vs 7.8 ms per update against 256)
   static const long sk_steps = getenv("DHW_SGEMM_SPLIT_STEPS") ? atol(getenv("DHW_SGEMM_SPLIT_STEPS")) : 8;
+  if (g.act_out && g.accumulate) return hipErrorInvalidValue;
   if (g.accumulate && !g.addend && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
   if (ksplit < 1) ksplit = 1;
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
@@ -1199,8 +1207,8 @@ hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam,
   return hipGetLastError();
 }
 hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
-                              float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, mean, rstd);
+                              float* act_out, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, mean, rstd);
   return hipGetLastError();
 }
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,

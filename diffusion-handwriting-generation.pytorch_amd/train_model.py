@@ -108,7 +108,7 @@ class Tape:
 
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
              nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False,
-             rowsum=None, addend=None):
+             rowsum=None, addend=None, act_out=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
 
@@ -127,7 +127,8 @@ class Tape:
                           Bm.data_ptr() + b_off * _F, sbk, sbn, zb[0], zb[1], sbt, b_shift, b_z_shift,
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
-                          addend.data_ptr() if addend is not None else None, rowsum.data_ptr() if rowsum is not None else None)
+                          act_out.data_ptr() if act_out is not None else None, addend.data_ptr() if addend is not None else None,
+                          rowsum.data_ptr() if rowsum is not None else None)
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
@@ -158,20 +159,35 @@ class Tape:
         dv, acc = self.into(v)
         self.call("dhw_op_add", dy.data_ptr(), None, dy.numel(), dv.data_ptr(), acc)
 
+    def _silu_of(self, y: "Var", buf: torch.Tensor) -> "Var":
+        """The Var of SiLU(y) whose values the kernel that produced y wrote into ``buf`` in the same pass (``silu_out`` of linear /
+        conv3 / ln_film_cols); its backward is the stand-alone SiLU's (recorded after y's, so it runs first and adds into y.g)."""
+        ya = Var(buf)
+        n = buf.numel()
+
+        def bwd():
+            dx, acc = self.into(y)
+            self.call("dhw_op_unary_bwd", 0, ya.g.data_ptr(), y.d.data_ptr(), n, dx.data_ptr(), acc)
+        self.record(ya, bwd)
+        return ya
+
     # ---- differentiable ops ------------------------------------------------------------------------------------------
-    def linear(self, x: Var, W: Var, b: Var | None, addend: Var | None = None) -> Var:
+    def linear(self, x: Var, W: Var, b: Var | None, addend: Var | None = None, silu_out: bool = False):
         """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]; ``addend`` [R, N]: the residual added to the result
         in the GEMM's output pass (y = x W^T + b + addend)."""
         R, K = x.d.shape
         N = W.d.shape[0]
-        if addend is not None and -(-R // 64) * -(-N // 64) < 64 and K >= 512:   # (split-K output: the add stays a pass of its own)
-            return self.add(self.linear(x, W, b), addend)
+        if (addend is not None or silu_out) and -(-R // 64) * -(-N // 64) < 64 and K >= 512:   # (split-K output: separate passes)
+            y = self.linear(x, W, b)
+            y = self.add(y, addend) if addend is not None else y
+            return (y, self.silu(y)) if silu_out else y
         # few output tiles and a long contraction (sigma_ffn's 2048 -> 32): zero the output and let the GEMM split K over
         # workgroups with atomics, instead of one workgroup walking all of K
         split = -(-R // 64) * -(-N // 64) < 64 and K >= 512
         y = Var(torch.zeros(R, N, device=self.dev) if split else self.new(R, N))
+        act = self.new(R, N) if silu_out else None     # ``silu_out``: also returns SiLU(y), written by the same GEMM pass
         self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None, acc=split,
-                  addend=addend.d if addend is not None else None)
+                  addend=addend.d if addend is not None else None, act_out=act)
 
         def bwd():
             dy = y.g
@@ -185,9 +201,9 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
-        return y
+        return (y, self._silu_of(y, act)) if silu_out else y
 
-    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None) -> Var:
+    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False):
         """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
         have any strides: TrainModel keeps the Conv1d weights as [tap][Cout][Cin] in memory (unit stride along Cin), which makes the
         weight the 16-byte-load operand of all three GEMMs; a torch-contiguous W works too (scalar loads, stride-3 stores)."""
@@ -196,9 +212,10 @@ class Tape:
         sco, sci, st = W.d.stride()
         y = Var(self.new(R, Cout))
         merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
+        act = self.new(R, Cout) if silu_out and merged else None
         if merged:
             self.gemm(x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
-                      sbt=st, lr=L, addend=addend.d if addend is not None else None)
+                      sbt=st, lr=L, addend=addend.d if addend is not None else None, act_out=act)
         else:
             for t in range(3):
                 self.gemm(x.d, 0, Cin, 1, W.d, t * st, sci, sco, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
@@ -224,7 +241,9 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
-        return y
+        if not silu_out:
+            return y
+        return (y, self._silu_of(y, act)) if act is not None else (y, self.silu(y))
 
     def unary(self, kind: int, x: Var) -> Var:
         y = Var(torch.empty_like(x.d), leaf=x.leaf)     # a function of inputs only needs no gradient either
@@ -312,7 +331,7 @@ class Tape:
         self.record(y, bwd)
         return y
 
-    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, addend: Var | None = None) -> Var:
+    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, addend: Var | None = None, silu_out: bool = False):
         """LayerNorm followed by FiLM (every EncoderLayer / TextStyleEncoder pairs them: model.py:44-58, text_style.py:98-110) in one
         pass each way; the normalised rows are recomputed in the backward from the saved mean / rstd."""
         R, Cc = x.d.shape
@@ -320,8 +339,10 @@ class Tape:
         y = Var(torch.empty_like(x.d))
         mean, rstd = self.new(R), self.new(R)
         base = table.d.data_ptr()
+        act = torch.empty_like(x.d) if silu_out else None
         self.call("dhw_op_ln_film", x.d.data_ptr(), B, L, Cc, base + col_g * _F, base + col_b * _F, TOT,
-                  addend.d.data_ptr() if addend is not None else None, y.d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+                  addend.d.data_ptr() if addend is not None else None, y.d.data_ptr(), act.data_ptr() if silu_out else None,
+                  mean.data_ptr(), rstd.data_ptr())
 
         def bwd():
             dx, acc = self.into(x)
@@ -331,7 +352,7 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, y.g)
         self.record(y, bwd)
-        return y
+        return (y, self._silu_of(y, act)) if silu_out else y
 
     def layernorm(self, x: Var) -> Var:
         R, Cc = x.d.shape
@@ -515,12 +536,14 @@ class TrainModel:
             self.pe(Lt, d, 1.0)
 
     # ---- modules ---------------------------------------------------------------------------------------------------------
-    def _lin(self, t, x, name, addend=None):
-        return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"), addend)
+    def _lin(self, t, x, name, addend=None, silu_out=False):
+        return t.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"), addend, silu_out)
 
-    def _ffn(self, t, x, name, addend=None):
-        """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear (+ the residual that follows it, in the last GEMM)."""
-        return self._lin(t, t.silu(self._lin(t, t.silu(x), name + ".1")), name + ".3", addend)
+    def _ffn(self, t, x, name, addend=None, x_act=None):
+        """ff_network (utils/nn.py:145-175): SiLU -> Linear -> SiLU -> Linear (+ the residual that follows it, in the last GEMM).
+        ``x_act``: SiLU(x) where the pass that produced x wrote it already; the inner SiLU comes out of the first GEMM's pass."""
+        _, ha = self._lin(t, x_act if x_act is not None else t.silu(x), name + ".1", silu_out=True)
+        return self._lin(t, ha, name + ".3", addend)
 
     def _film_table(self, t, sigma, B):
         """gamma / beta of all AffineTransformLayers for this sigma: one launch forward, two backward (instead of 76 small
@@ -535,19 +558,19 @@ class TrainModel:
     def _affine(self, t, x, sigma, name, B, act=False, addend=None):
         return t.film_cols(x, self._film, *self.film_cols[name], B, act, addend)
 
-    def _ln_affine(self, t, x, sigma, name, B, addend=None):
+    def _ln_affine(self, t, x, sigma, name, B, addend=None, silu_out=False):
         """affine(layernorm(x)) (+ addend) as one fused pass (LN statistics span at most 512 channels here)."""
-        return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend)
+        return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend, silu_out)
 
     def _mha(self, t, q, k, v, name, B, H, mask=None, addend=None):
         o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
         return self._lin(t, o, name + ".dense", addend)
 
-    def _convblock(self, t, x, sigma, name, B, L):
-        """cnn.py:64-87."""
+    def _convblock(self, t, x, sigma, name, B, L, x_act=None):
+        """cnn.py:64-87.  ``x_act``: SiLU(x) where the pass that produced x wrote it already."""
         conv = lambda v, n: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L)   # noqa: E731
         skip = conv(x, "conv_skip")
-        h = self._affine(t, conv(t.silu(x), "conv1"), sigma, name + ".affine1", B, act=True)      # SiLU(affine1(.)) in one pass
+        h = self._affine(t, conv(x_act if x_act is not None else t.silu(x), "conv1"), sigma, name + ".affine1", B, act=True)   # SiLU(affine1(.)) in one pass
         h = self._affine(t, conv(h, "conv2"), sigma, name + ".affine2", B, act=True)
         return self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B, addend=skip)   # affine3(fc(h)) + conv_skip(x)
 
@@ -575,12 +598,12 @@ class TrainModel:
         x2 = self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B, addend=x)        # the residual adds ride on the
         x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)                                         # passes / GEMMs around them
         if self.drop_rate == 0.0:
-            x3 = self._ln_affine(t, self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H, addend=x2), sigma, name + ".affine2", B)
-            x4 = self._ffn(t, x3, name + ".ffn", addend=x3)
+            x3, x3a = self._ln_affine(t, self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H, addend=x2), sigma, name + ".affine2", B, silu_out=True)
+            x4 = self._ffn(t, x3, name + ".ffn", addend=x3, x_act=x3a)
         else:       # (the dropout sits between the GEMM and the add)
             x3 = self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H)
-            x3 = self._ln_affine(t, t.add(x2, self._drop(t, x3, B)), sigma, name + ".affine2", B)
-            x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn"), B), x3)
+            x3, x3a = self._ln_affine(t, t.add(x2, self._drop(t, x3, B)), sigma, name + ".affine2", B, silu_out=True)
+            x4 = t.add(self._drop(t, self._ffn(t, x3, name + ".ffn", x_act=x3a), B), x3)
         return self._ln_affine(t, x4, sigma, name + ".affine3", B)
 
     def _text_style(self, t, ids, style, sigma, keep, B):
@@ -593,8 +616,8 @@ class TrainModel:
         stf = self._ln_affine(t, stf, sigma, n + ".affine1", B)
         tx = t.embedding(ids, self.p[n + ".emb.weight"])
         tx = self._ln_affine(t, tx, sigma, n + ".affine2", B)
-        tx = self._ln_affine(t, self._mha(t, tx, stf, stf, n + ".mha", B, 8, addend=tx), sigma, n + ".affine3", B)
-        return self._ln_affine(t, self._ffn(t, tx, n + ".text_ffn"), sigma, n + ".affine4", B)
+        tx, txa = self._ln_affine(t, self._mha(t, tx, stf, stf, n + ".mha", B, 8, addend=tx), sigma, n + ".affine3", B, silu_out=True)
+        return self._ln_affine(t, self._ffn(t, tx, n + ".text_ffn", x_act=txa), sigma, n + ".affine4", B)
 
     # ---- forward / backward ----------------------------------------------------------------------------------------------
     def check_tokens(self, text: torch.Tensor):
@@ -632,8 +655,8 @@ class TrainModel:
         self._film_table(t, sigma_v, B)
         txt = t.silu(self._text_style(t, ids, sty, sigma_v, keep, B))                  # SiLU([B*Lt, 2 c2]): every EncoderLayer's text_dense starts
                                                                                        # with it (model.py:38) — once, not once per layer
-        x = self._lin(t, x_in, "input_dense")
-        h1 = self._convblock(t, x, sigma_v, "enc1", B, L)
+        x, xa = self._lin(t, x_in, "input_dense", silu_out=True)
+        h1 = self._convblock(t, x, sigma_v, "enc1", B, L, x_act=xa)
         h2 = self._convblock(t, t.resample(0, h1), sigma_v, "enc2", B, L // 2)
         h2 = self._encoder(t, h2, txt, sigma_v, mask, "enc3", B, 3, 4)
         h3 = self._convblock(t, t.resample(0, h2), sigma_v, "enc4", B, L // 4)
@@ -642,10 +665,14 @@ class TrainModel:
         for i in range(self.num_layers):
             x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1)
         # upsample(x) + skip_conv(h): the add rides on the skip convolution's output pass
-        skip = lambda v, n, Lr, up: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr, addend=up)   # noqa: E731
-        x = self._convblock(t, skip(h3, "skip_conv3", L // 4, t.resample(2, x)), sigma_v, "dec3", B, L // 4)
-        x = self._convblock(t, skip(h2, "skip_conv2", L // 2, t.resample(2, x)), sigma_v, "dec2", B, L // 2)
-        x = self._convblock(t, skip(h1, "skip_conv1", L, t.resample(2, x)), sigma_v, "dec1", B, L)
+        # (and SiLU of the sum, which the decoder block's conv1 starts with, is its second output)
+        skip = lambda v, n, Lr, up: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr, addend=up, silu_out=True)   # noqa: E731
+        x, xa = skip(h3, "skip_conv3", L // 4, t.resample(2, x))
+        x = self._convblock(t, x, sigma_v, "dec3", B, L // 4, x_act=xa)
+        x, xa = skip(h2, "skip_conv2", L // 2, t.resample(2, x))
+        x = self._convblock(t, x, sigma_v, "dec2", B, L // 2, x_act=xa)
+        x, xa = skip(h1, "skip_conv1", L, t.resample(2, x))
+        x = self._convblock(t, x, sigma_v, "dec1", B, L, x_act=xa)
         self._score = self._lin(t, x, "output_dense")
         self._pen = t.sigmoid(self._lin(t, x, "pen_lifts_dense.0"))
         return self._score.d.view(B, L, 2), self._pen.d.view(B, L)

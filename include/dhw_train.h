@@ -90,6 +90,8 @@ typedef struct {
   const float* bias; float alpha; int accumulate;
   int bf16;   /* 0: exact-f32 MFMA.  1: the operands (fp32 in memory) are rounded to bf16 on their way into LDS and contracted on
                  the bf16 MFMA with fp32 accumulation — mixed-precision training with fp32 master weights */
+  float* act_out;        /* NULL, or an array laid out as C that receives SiLU(value written to C): the activation that follows the Linear /
+                            Conv1d in ff_network / ConvBlock, written in the same pass (accumulate must be 0) */
   const float* addend;   /* NULL, or an array laid out as C: C = alpha A B + bias + addend — a residual add in the GEMM's output pass */
   float* rowsum;   /* NULL, or [M]: rowsum[m] += sum_k A(0,m,k) (batch z = 0 only) — the bias gradient of a Linear / Conv1d comes out
                       of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum) */
@@ -118,7 +120,7 @@ int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long 
 int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* dx,
                         int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend /* or NULL */, float* y,
-                   float* mean, float* rstd, void* hip_stream);
+                   float* act_out /* or NULL: SiLU(y) */, float* mean, float* rstd, void* hip_stream);
 int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,
                        float* dx, int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* hip_stream);

@@ -123,7 +123,8 @@ def test_elementwise_norm_and_resampling_ops():
 
 def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
     """``addend`` of linear / conv3 (dhw_gemm_desc.addend), film_cols and ln_film_cols: y = op(x) + r, d r = d y, with fan-in on r
-    (model.py:44-58 and cnn.py:87 chain exactly these); sizes with edge tiles (scalar output path) and interior tiles (vector path)."""
+    (model.py:44-58 and cnn.py:87 chain exactly these), and ``silu_out`` (dhw_gemm_desc.act_out, act_out of dhw_op_ln_film): SiLU(y) as
+    a second output of the same pass; sizes with edge tiles (scalar output path) and interior tiles (vector path)."""
     g = torch.Generator().manual_seed(11)
     for B, L, Cin, Cout in ((2, 24, 64, 96), (4, 64, 128, 128)):
         R = B * L
@@ -136,17 +137,19 @@ def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
         table = torch.randn(B, 4 * Cout, generator=g, requires_grad=True)     # gamma | beta for the FiLM, gamma | beta for LN + FiLM
 
         def build(t, x, r, W, W3, b, b3, table):
-            h = t.linear(x, W, b, addend=r)                                    # x W^T + b + r
-            h = t.conv3(h, W3, b3, L, addend=r)                                # second consumer of r: its gradient is a fan-in
-            h = t.film_cols(h, table, 0, Cout, B, act=True, addend=r)
-            return t.ln_film_cols(h, table, 2 * Cout, 3 * Cout, B, addend=h)
+            h, ha = t.linear(x, W, b, addend=r, silu_out=True)                 # x W^T + b + r, and SiLU of it from the same pass
+            h2, h2a = t.conv3(ha, W3, b3, L, addend=h, silu_out=True)          # both outputs of the Linear are consumed
+            h3 = t.film_cols(h2a, table, 0, Cout, B, act=True, addend=r)       # second consumer of r: its gradient is a fan-in
+            y, ya = t.ln_film_cols(h3, table, 2 * Cout, 3 * Cout, B, addend=h2, silu_out=True)
+            return t.add(y, ya)
 
         y, vs, dy = _run(build, (x, r, W, W3, b, b3, table))
         h = F.linear(x, W, b) + r
-        h = F.conv1d(h.view(B, L, Cout).transpose(1, 2), W3, b3, padding="same").transpose(1, 2).reshape(R, Cout) + r
+        h2 = F.conv1d(F.silu(h).view(B, L, Cout).transpose(1, 2), W3, b3, padding="same").transpose(1, 2).reshape(R, Cout) + h
         ga, be, ga2, be2 = (table[:, i * Cout:(i + 1) * Cout] for i in range(4))
-        h = F.silu(h.view(B, L, Cout) * ga[:, None] + be[:, None]).reshape(R, Cout) + r
-        ref = (F.layer_norm(h, (Cout,), eps=1e-6).view(B, L, Cout) * ga2[:, None] + be2[:, None]).reshape(R, Cout) + h
+        h3 = F.silu(F.silu(h2).view(B, L, Cout) * ga[:, None] + be[:, None]).reshape(R, Cout) + r
+        yr = (F.layer_norm(h3, (Cout,), eps=1e-6).view(B, L, Cout) * ga2[:, None] + be2[:, None]).reshape(R, Cout) + h2
+        ref = yr + F.silu(yr)
         ref.backward(dy)
         _close(y.d, ref)
         for v, t_ref in zip(vs, (x, r, W, W3, b, b3, table)):
