@@ -253,16 +253,17 @@ def test_whole_model_gradients_match_the_reference_autograd(golden_dir, fixture)
             _close(model.p[k[2:]].g, torch.from_numpy(f[k]), 1e-3)
 
 
-def test_gradients_at_the_benchmarked_shape_match_the_oracle_autograd():
-    """BASELINE configs[4] at the shape `bench.py --train` runs (L=480, Lt=50, S=14; B=4 of the 32 per GPU so the oracle's
-    autograd pass fits the test budget): forward + loss + backward through the library against oracle/ref_cpu.forward +
+@pytest.mark.parametrize("B", [4, 32])
+def test_gradients_at_the_benchmarked_shape_match_the_oracle_autograd(B):
+    """BASELINE configs[4] at the shape `bench.py --train` runs (L=480, Lt=50, S=14; B=32 is the bench's per-GPU batch itself — its
+    GEMM shapes pick other tile sizes and split-K factors than B=4's): forward + loss + backward through the library against oracle/ref_cpu.forward +
     the reference's loss (loss.py:29-37) under torch autograd on the CPU, same seeded weights / inputs / eps / abar / style
     keep-mask.  The small fixtures (model_grad.npz: B=2, L=64, Lt=10) never reach the split-K weight-gradient path over
     thousands of rows with its fp32 atomics, nor the multi-block attention of L/2 = 240 keys; this does.  Every one of the
     323 parameter gradients: norm and projection on a fixed random direction, relative to the gradient's own norm
     (floored at 1e-4 of the largest).  Tolerance 2e-4 (fp32 accumulation order over 1920-row contractions; measured 6.6e-6)."""
     from oracle import ref_cpu
-    B, L, Lt, S = 4, 480, 50, 14
+    L, Lt, S = 480, 50, 14
     sd_np = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
     inp = spec.synthetic_inputs(B, L, Lt, S=S, seed=21, pad=3)
     g = torch.Generator().manual_seed(5)
