@@ -28,16 +28,6 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="GEMM operand precision (fp32 = the reference's)")
     a = ap.parse_args(argv)
-    # the host side draws abar and assembles batches with small torch CPU ops: one thread per visible core on a box whose
-    # cgroup grants fewer makes each of them take milliseconds
-    import os
-    import torch
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        cores = os.cpu_count() if quota == "max" else max(1, int(int(quota) / int(period)))
-    except (OSError, ValueError):
-        cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(cores, 16)))
     dhg_amd.train_model.fit(a.config, a.data, a.out, steps=a.steps, init=a.init, seed=a.seed, precision=a.precision)
 
 
