@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r uses GPU r %% device_count, gloo instead of RCCL "
                          "for the barrier (RCCL refuses two ranks on one device); the line is marked, never a scaling result")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (RCCL) even for one rank: runs the barrier / max-over-ranks path on a 1-GPU box")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
@@ -126,9 +128,23 @@ def launch(args, argv) -> int:
 
 
 # ---------------------------------------------------------------------------------------------- one rank
+_JSON_OUT = None   # the rank's real stdout (worker() points fd 1 at stderr so that only the JSON line reaches stdout)
+
+
+def emit(line: str):
+    print(line, file=_JSON_OUT or sys.stdout, flush=True)
+
+
 def worker(args):
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # a stuck run says where
+    # ONE JSON line on stdout is the contract; libraries do not know it (RCCL prints its version banner to stdout under
+    # NCCL_DEBUG=VERSION, which the GPU boxes export): everything written to fd 1 from here on goes to stderr, the line goes
+    # to a private duplicate of the original stdout.
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,10 +159,13 @@ def worker(args):
         di = (local_rank % max(1, torch.cuda.device_count())) if args.share_gpu else (local_rank if world > 1 else 0)
         torch.cuda.set_device(di)
         dev = torch.device("cuda", di)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.stub or args.share_gpu:
             dist.init_process_group("gloo")
@@ -265,7 +284,7 @@ def worker(args):
                 res["train_step"] = train_step_figure(args, dev)
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args, spec)
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -355,7 +374,7 @@ def train_worker(args, dev, dist, rank, world):
             res["bf16_mode"] = {"value": B / d2, "unit": "samples/s", "ms_per_step": d2 * 1e3, "steps": args.steps}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_train_baseline(args, spec)
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

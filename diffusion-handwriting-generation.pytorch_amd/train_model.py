@@ -724,7 +724,7 @@ def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch
     out, d_score, d_pen = loss_fn(eps, score, pen, pen_pred, alphas)
     model.backward(d_score, d_pen)
     grads = model.grads()
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
         allreduce_grads(grads)
     model.last_grad_norm = float(optimizer.step(grads, noam_lr(step, d_model, warmup, lr_mul)))   # (one host sync per update)
     return out
@@ -777,7 +777,7 @@ class GraphedTrainStep:
         """Gradient averaging across ranks (one all-reduce of the flat 40 MB buffer: RCCL over xGMI) and the optimizer: three
         launches, issued eagerly after the graph so that the collective stays outside the capture."""
         m = self.model
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
             allreduce_grads(m.grads())
         self.opt.step_dev(m.grads(), self.hyper, self.sqnorm)
 

@@ -218,3 +218,19 @@ def test_wave_specialised_encoder_kernel_matches_the_default(tmp_path):
     scale = float(np.abs(a[..., :2]).max())
     assert float(np.abs(a[..., :2] - b[..., :2]).max()) <= 0.02 * scale
     assert float(np.abs(a[..., 2] - b[..., 2]).max()) <= 0.01        # pen-lift probabilities
+
+
+def test_bench_prints_exactly_one_json_line_with_rccl_initialised():
+    """`bench.py --force-dist`: the multi-GPU form's process group (backend "nccl" = RCCL: barrier and max-over-ranks of the wall time)
+    on a one-rank group, so the collective path runs on a 1-GPU box.  The GPU boxes export NCCL_DEBUG=VERSION and RCCL prints its
+    banner to STDOUT: the rank must still put exactly ONE line on stdout, the JSON line (bench.py routes fd 1 to stderr)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NCCL_DEBUG="VERSION", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp32",
+                        "--no-train-step", "--no-kernel-profile"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["metric"].startswith("stroke-points")
