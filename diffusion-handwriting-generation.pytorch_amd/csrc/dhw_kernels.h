@@ -228,6 +228,8 @@ struct OpGemm {
   float* C; long scm, scn, sczo, sczi;
   int M, N, K, nzo, nzi, lr, taps;
   const float* bias; float alpha; int accumulate, bf16;
+  const float* dsilu_of; // or null: the product is multiplied by SiLU'(dsilu_of[m][n]) (C's layout) before it is written / added: the data gradient
+                         // of a Linear / Conv1d whose input was SiLU(u) lands directly in du
   float* act_out;        // or null: SiLU of the value written to C, same layout (the activation that follows a Linear / Conv1d; not with accumulate / split-K)
   const float* addend;   // or null: C = alpha A B + bias + addend (C's layout; a residual add in the output pass; no split-K then)
   float* rowsum;   // or null: rowsum[m] += sum_k A(0,m,k) (batch z = 0) — a Linear / Conv1d bias gradient out of its weight-gradient GEMM

@@ -269,7 +269,7 @@ int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
   g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.sbt = d->sbt; g.b_shift = d->b_shift; g.b_z_shift = d->b_z_shift;
   g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
   g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr; g.taps = d->taps;
-  g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.act_out = d->act_out; g.stamps = nullptr;
+  g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.act_out = d->act_out; g.dsilu_of = d->dsilu_of; g.stamps = nullptr;
   THIP(launch_sgemm(g, (hipStream_t)hip_stream));
   return 0;
 }

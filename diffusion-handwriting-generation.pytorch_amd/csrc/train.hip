@@ -749,8 +749,9 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   // interior tile of a row-major output without split-K: 16 bytes per lane, 4 store instructions per thread instead of 16
   const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend / act_out: launch_sgemm)
   float* Ao = g.act_out ? g.act_out + zo * g.sczo + zi * g.sczi : nullptr;
+  const float* Du = g.dsilu_of ? g.dsilu_of + zo * g.sczo + zi * g.sczi : nullptr;
   const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GM <= g.M && n0 + GT <= g.N &&
-                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | reinterpret_cast<uintptr_t>(Ao) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
+                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | reinterpret_cast<uintptr_t>(Ao) | reinterpret_cast<uintptr_t>(Du) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
   if (vec_out) {
     const int c4 = 4 * (t & 15);
     const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
@@ -760,6 +761,10 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
       f32x4* c = reinterpret_cast<f32x4*>(C + (long)(m0 + rr) * g.scm + n0 + c4);
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * CS + c4) * g.alpha + bias;
       if (Dd) v += *reinterpret_cast<const f32x4*>(Dd + (long)(m0 + rr) * g.scm + n0 + c4);
+      if (Du) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(Du + (long)(m0 + rr) * g.scm + n0 + c4);
+        v = v * (f32x4){dsilu_f(u[0]), dsilu_f(u[1]), dsilu_f(u[2]), dsilu_f(u[3])};
+      }
       *c = g.accumulate ? *c + v : v;
       if (Ao) *reinterpret_cast<f32x4*>(Ao + (long)(m0 + rr) * g.scm + n0 + c4) = (f32x4){silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
     }
@@ -776,6 +781,7 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
         float* c = cn + (long)m * g.scm;
         float v = g.alpha * Cs[rr * CS + lane] + bias;
         if (Dd) v += Dd[(long)n * g.scn + (long)m * g.scm];
+        if (Du) v *= dsilu_f(Du[(long)n * g.scn + (long)m * g.scm]);
         if (ksplit > 1) atomicAdd(c, v);
         else *c = g.accumulate ? *c + v : v;
         if (Ao) Ao[(long)n * g.scn + (long)m * g.scm] = silu_f(v);
@@ -1131,7 +1137,8 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   static const long sk_target = getenv("DHW_SGEMM_SPLIT_WGS") ? atol(getenv("DHW_SGEMM_SPLIT_WGS")) : 512;   // (two workgroups per CU: 7.6 vs 7.8 ms per update against 256)
   static const long sk_steps = getenv("DHW_SGEMM_SPLIT_STEPS") ? atol(getenv("DHW_SGEMM_SPLIT_STEPS")) : 8;
   if (g.act_out && g.accumulate) return hipErrorInvalidValue;
-  if (g.accumulate && !g.addend && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
+  if (g.dsilu_of && (g.bias || g.addend)) return hipErrorInvalidValue;   // (a factor on the product alone)
+  if (g.accumulate && !g.addend && !g.dsilu_of && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
   if (ksplit < 1) ksplit = 1;
   const int kslice = ((g.K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
   ksplit = (g.K + kslice - 1) / kslice;

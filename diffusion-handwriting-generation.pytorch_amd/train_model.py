@@ -29,16 +29,19 @@ _F = 4  # bytes per element
 # DHW_TRAIN_WGRAD_SIDE=1: weight-gradient GEMMs on the tape's side stream (parallel hipGraph branches beside the data-gradient
 # chain).  Measured slower (9.93 vs 9.12 ms per update, r3): the GEMMs already fill the CUs, the branches only interleave them.
 WGRAD_SIDE = os.environ.get("DHW_TRAIN_WGRAD_SIDE", "0") == "1"
+# DHW_TRAIN_FUSE_DSILU=0: SiLU's backward as its own pass again instead of a factor in the consuming GEMM's data-gradient output (A/B)
+FUSE_DSILU = os.environ.get("DHW_TRAIN_FUSE_DSILU", "1") != "0"
 
 class Var:
     """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient.  ``leaf``: a network input
     whose gradient nobody needs (the backward sweep skips the kernels that would only produce it)."""
-    __slots__ = ("d", "g", "leaf")
+    __slots__ = ("d", "g", "leaf", "pre")
 
     def __init__(self, d: torch.Tensor, leaf: bool = False):
         self.d = d
         self.g = None
         self.leaf = leaf
+        self.pre = None     # self = SiLU(pre): a GEMM that consumes self sends its data gradient straight to pre (dhw_gemm_desc.dsilu_of)
 
     def grad(self) -> torch.Tensor:
         if self.g is None:
@@ -108,7 +111,7 @@ class Tape:
 
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
              nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False,
-             rowsum=None, addend=None, act_out=None):
+             rowsum=None, addend=None, act_out=None, dsilu_of=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
 
@@ -128,7 +131,7 @@ class Tape:
                           Cm.data_ptr() + c_off * _F, scm, scn, zc[0], zc[1],
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
                           act_out.data_ptr() if act_out is not None else None, addend.data_ptr() if addend is not None else None,
-                          rowsum.data_ptr() if rowsum is not None else None)
+                          dsilu_of.data_ptr() if dsilu_of is not None else None, rowsum.data_ptr() if rowsum is not None else None)
         _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
@@ -163,6 +166,7 @@ class Tape:
         """The Var of SiLU(y) whose values the kernel that produced y wrote into ``buf`` in the same pass (``silu_out`` of linear /
         conv3 / ln_film_cols); its backward is the stand-alone SiLU's (recorded after y's, so it runs first and adds into y.g)."""
         ya = Var(buf)
+        ya.pre = y if FUSE_DSILU else None
         n = buf.numel()
 
         def bwd():
@@ -192,8 +196,12 @@ class Tape:
         def bwd():
             dy = y.g
             if not x.leaf:
-                dx, acc = self.into(x)
-                self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)             # dx (+)= dy W
+                if x.pre is not None:       # x = SiLU(u): d u (+)= (dy W) * SiLU'(u) in the GEMM's output pass, x's own backward has nothing to do
+                    dx, acc = self.into(x.pre)
+                    self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc, dsilu_of=x.pre.d)
+                else:
+                    dx, acc = self.into(x)
+                    self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)         # dx (+)= dy W
             dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
             if WGRAD_SIDE:
                 self.fork(dy, x.d)
@@ -224,13 +232,14 @@ class Tape:
         def bwd():
             dy, dW, db = y.g, W.grad(), b.grad()
             gco, gci, gt = dW.stride()
-            dx, acc = self.into(x)
+            fuse = merged and x.pre is not None    # x = SiLU(u): the merged data-gradient GEMM writes d u itself
+            dx, acc = self.into(x.pre if fuse else x)
             if WGRAD_SIDE:
                 self.fork(dy, x.d)
             # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
             if merged:
                 self.gemm(dy, 0, Cout, 1, W.d, 0, sco, sci, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
-                          sbt=st, lr=L)
+                          sbt=st, lr=L, dsilu_of=x.pre.d if fuse else None)
                 self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, gco, gci, Cout, Cin, R, acc=True, nzi=3, zc=(0, gt), b_shift=-1,
                           b_z_shift=1, lr=L, rowsum=db, side=WGRAD_SIDE)                            # the taps as the inner batch index; db rides along
             else:
@@ -249,6 +258,8 @@ class Tape:
         y = Var(torch.empty_like(x.d), leaf=x.leaf)     # a function of inputs only needs no gradient either
         n = x.d.numel()
         self.call("dhw_op_unary", kind, x.d.data_ptr(), n, y.d.data_ptr())
+        if kind == 0 and not x.leaf and FUSE_DSILU:
+            y.pre = x
         saved = x.d if kind == 0 else y.d
         def bwd():
             if x.leaf:
@@ -695,6 +706,7 @@ class _ViewVar(Var):
         self.d = base.d.view(*shape)
         self.g = None
         self.leaf = base.leaf
+        self.pre = None
 
     def grad(self):
         if self.g is None:

@@ -93,6 +93,8 @@ typedef struct {
   float* act_out;        /* NULL, or an array laid out as C that receives SiLU(value written to C): the activation that follows the Linear /
                             Conv1d in ff_network / ConvBlock, written in the same pass (accumulate must be 0) */
   const float* addend;   /* NULL, or an array laid out as C: C = alpha A B + bias + addend — a residual add in the GEMM's output pass */
+  const float* dsilu_of; /* NULL, or an array laid out as C: the product is multiplied by SiLU'(dsilu_of) before it is written / added — the
+                            data gradient of a Linear / Conv1d whose input was SiLU(u) goes straight into du (no bias / addend with it) */
   float* rowsum;   /* NULL, or [M]: rowsum[m] += sum_k A(0,m,k) (batch z = 0 only) — the bias gradient of a Linear / Conv1d comes out
                       of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum) */
 } dhw_gemm_desc;

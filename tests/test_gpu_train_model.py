@@ -159,7 +159,7 @@ def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
 def test_gemm_kernel_paths_against_float64_matmul():
     """dhw_op_gemm called directly over a sweep that reaches every path of the kernel: 64- and 32-row tiles, interior (unmasked K loop,
     16-byte output) and ragged tiles, K of whole and partial steps, the three operand orientations (k-major / m-major LDS tiles),
-    split-K with atomics (accumulating outputs), addend, act_out and rowsum."""
+    split-K with atomics (accumulating outputs), addend, act_out, dsilu_of and rowsum."""
     import ctypes as C
     import itertools
     from dhg_amd import _lib
@@ -179,10 +179,16 @@ def test_gemm_kernel_paths_against_float64_matmul():
             rs = torch.zeros(M, device=DEV)
             act = torch.empty(M, N, device=DEV) if not acc else None
             if not acc:
-                ref = ref + D.double()
+                ref = ref + D.double()                  # addend (non-accumulating launches); accumulating ones test dsilu_of instead:
+            else:                                       # C += (A B) * SiLU'(D)
+                sg = torch.sigmoid(D.double())
+                ref = Cm.cpu().double() + (A.double() @ Bm.double()) * (sg * (1 + D.double() * (1 - sg)))
             d = _lib.GemmDesc(As.data_ptr(), sam, sak, 0, 0, 0, 0, Bs.data_ptr(), sbk, sbn, 0, 0, 0, 0, 0, Cm.data_ptr(), N, 1, 0, 0,
-                              M, N, K, 1, 1, 0, 1, None, 1.0, acc, 0, act.data_ptr() if act is not None else None,
-                              Dd.data_ptr() if not acc else None, rs.data_ptr())
+                              M, N, K, 1, 1, 0, 1, None, 1.0, acc, 0)
+            d.act_out = act.data_ptr() if act is not None else None
+            d.addend = Dd.data_ptr() if not acc else None
+            d.dsilu_of = Dd.data_ptr() if acc else None
+            d.rowsum = rs.data_ptr()
             assert lib.dhw_op_gemm(C.byref(d), None) == 0
             torch.cuda.synchronize()
             tol = 2e-5 * max(float(ref.abs().max()), 1e-6)
