@@ -98,7 +98,7 @@ SIGNATURES = {
     "dhw_op_film_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "dhw_op_film_act": (C.c_int, [_P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dhw_op_film_act_bwd": (C.c_int, [_P, _P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
-    "dhw_op_ln_film": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _LL, _P, _P, _P, _P, _P, _P]),
+    "dhw_op_ln_film": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dhw_op_ln_film_bwd": (C.c_int, [_P, _P, _P, _P, _P, _LL, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "dhw_op_layernorm": (C.c_int, [_P, _LL, C.c_int, _P, _P, _P, _P]),
     "dhw_op_layernorm_bwd": (C.c_int, [_P, _P, _P, _LL, C.c_int, _P, C.c_int, _P]),

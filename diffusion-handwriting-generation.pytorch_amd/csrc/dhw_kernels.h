@@ -253,7 +253,7 @@ hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* be
 hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
                                int accumulate, float* dgam, float* dbet, hipStream_t st);
 hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
-                              float* act_out, float* mean, float* rstd, hipStream_t st);
+                              float* act_out, const float* pe, float* pe_out, float* mean, float* rstd, hipStream_t st);
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,
                               float* dx, int accumulate, float* dgam, float* dbet, hipStream_t st);
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st);

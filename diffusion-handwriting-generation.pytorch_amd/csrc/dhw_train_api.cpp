@@ -317,9 +317,9 @@ int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, con
   return 0;
 }
 int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend, float* y, float* act_out,
-                   float* mean, float* rstd, void* st) {
-  OPCHECK(x && gamma && beta && y && mean && rstd && B > 0 && L > 0 && C > 0, "dhw_op_ln_film");
-  THIP(launch_ln_film_fwd(x, (long)B * L, C, gamma, beta, pstride, L, addend, y, act_out, mean, rstd, (hipStream_t)st));
+                   const float* pe, float* pe_out, float* mean, float* rstd, void* st) {
+  OPCHECK(x && gamma && beta && y && mean && rstd && B > 0 && L > 0 && C > 0 && (!pe_out || pe), "dhw_op_ln_film");
+  THIP(launch_ln_film_fwd(x, (long)B * L, C, gamma, beta, pstride, L, addend, y, act_out, pe, pe_out, mean, rstd, (hipStream_t)st));
   return 0;
 }
 int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,

@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void film_act_bwd_kernel(const float* d, const
 }
 // y = LayerNorm(x) gamma[b] + beta[b]  (eps 1e-6, no LN affine; one wave per row; mean / rstd kept for the backward)
 __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L,
-                                                           const float* addend, float* y, float* act_out, float* mean_out, float* rstd_out) {
+                                                           const float* addend, float* y, float* act_out, const float* pe, float* pe_out, float* mean_out, float* rstd_out) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -1008,6 +1008,7 @@ __global__ __launch_bounds__(256) void ln_film_fwd_kernel(const float* x, long r
     const float v = (xr[c] - mean) * rstd * gam[pb + c] + bet[pb + c] + (addend ? addend[row * C + c] : 0.f);
     y[row * C + c] = v;
     if (act_out) act_out[row * C + c] = silu_f(v);   // (the SiLU an ff_network opens with, utils/nn.py:145)
+    if (pe_out) pe_out[row * C + c] = v + pe[(row % L) * C + c];   // (x + PE: what the q / k projections of the next attention take, model.py:41-48)
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -1214,8 +1215,8 @@ hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam,
   return hipGetLastError();
 }
 hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
-                              float* act_out, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, mean, rstd);
+                              float* act_out, const float* pe, float* pe_out, float* mean, float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, pe, pe_out, mean, rstd);
   return hipGetLastError();
 }
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,

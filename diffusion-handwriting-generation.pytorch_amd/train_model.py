@@ -342,7 +342,8 @@ class Tape:
         self.record(y, bwd)
         return y
 
-    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, addend: Var | None = None, silu_out: bool = False):
+    def ln_film_cols(self, x: Var, table: Var, col_g: int, col_b: int, B: int, addend: Var | None = None, silu_out: bool = False,
+                     pe: torch.Tensor | None = None):
         """LayerNorm followed by FiLM (every EncoderLayer / TextStyleEncoder pairs them: model.py:44-58, text_style.py:98-110) in one
         pass each way; the normalised rows are recomputed in the backward from the saved mean / rstd."""
         R, Cc = x.d.shape
@@ -351,9 +352,10 @@ class Tape:
         mean, rstd = self.new(R), self.new(R)
         base = table.d.data_ptr()
         act = torch.empty_like(x.d) if silu_out else None
+        ype = torch.empty_like(x.d) if pe is not None else None     # ``pe`` [L, C]: also returns y + pe[l] (add_rows of the result) from the same pass
         self.call("dhw_op_ln_film", x.d.data_ptr(), B, L, Cc, base + col_g * _F, base + col_b * _F, TOT,
                   addend.d.data_ptr() if addend is not None else None, y.d.data_ptr(), act.data_ptr() if silu_out else None,
-                  mean.data_ptr(), rstd.data_ptr())
+                  pe.data_ptr() if pe is not None else None, ype.data_ptr() if pe is not None else None, mean.data_ptr(), rstd.data_ptr())
 
         def bwd():
             dx, acc = self.into(x)
@@ -363,7 +365,14 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, y.g)
         self.record(y, bwd)
-        return (y, self._silu_of(y, act)) if silu_out else y
+        outs = [y]
+        if silu_out:
+            outs.append(self._silu_of(y, act))
+        if pe is not None:
+            yp = Var(ype)
+            self.record(yp, lambda: self._grad_to(y, yp.g))     # d y (+)= d (y + pe)
+            outs.append(yp)
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     def layernorm(self, x: Var) -> Var:
         R, Cc = x.d.shape
@@ -569,9 +578,9 @@ class TrainModel:
     def _affine(self, t, x, sigma, name, B, act=False, addend=None):
         return t.film_cols(x, self._film, *self.film_cols[name], B, act, addend)
 
-    def _ln_affine(self, t, x, sigma, name, B, addend=None, silu_out=False):
+    def _ln_affine(self, t, x, sigma, name, B, addend=None, silu_out=False, pe=None):
         """affine(layernorm(x)) (+ addend) as one fused pass (LN statistics span at most 512 channels here)."""
-        return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend, silu_out)
+        return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend, silu_out, pe)
 
     def _mha(self, t, q, k, v, name, B, H, mask=None, addend=None):
         o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
@@ -602,12 +611,11 @@ class TrainModel:
         """EncoderLayer.forward (model.py:36-58); ``text`` is SiLU(text features) already."""
         d = x.d.shape[1]
         Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
-        tx = self._ln_affine(t, self._lin(t, text, name + ".text_dense"), sigma, name + ".affine0", B)   # text: SiLU(text features), shared
-        text_pe = t.add_rows(tx, self.pe(Lt, d, 1.0), B)
+        tx, text_pe = self._ln_affine(t, self._lin(t, text, name + ".text_dense"), sigma, name + ".affine0", B, pe=self.pe(Lt, d, 1.0))   # text: SiLU(text features), shared
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
-        x2 = self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B, addend=x)        # the residual adds ride on the
-        x2_pe = t.add_rows(x2, self.pe(Lx, d, pos_factor), B)                                         # passes / GEMMs around them
+        # the residual adds and the positional-encoding adds ride on the passes / GEMMs around them
+        x2, x2_pe = self._ln_affine(t, self._drop(t, x2, B), sigma, name + ".affine1", B, addend=x, pe=self.pe(Lx, d, pos_factor))
         if self.drop_rate == 0.0:
             x3, x3a = self._ln_affine(t, self._mha(t, x2_pe, x2_pe, x2, name + ".mha2", B, H, addend=x2), sigma, name + ".affine2", B, silu_out=True)
             x4 = self._ffn(t, x3, name + ".ffn", addend=x3, x_act=x3a)

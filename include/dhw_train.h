@@ -122,7 +122,8 @@ int dhw_op_film_act(const float* x, const float* gamma, const float* beta, long 
 int dhw_op_film_act_bwd(const float* dy, const float* x, const float* gamma, const float* beta, long long pstride, int B, int L, int C, int act, float* dx,
                         int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_ln_film(const float* x, int B, int L, int C, const float* gamma, const float* beta, long long pstride, const float* addend /* or NULL */, float* y,
-                   float* act_out /* or NULL: SiLU(y) */, float* mean, float* rstd, void* hip_stream);
+                   float* act_out /* or NULL: SiLU(y) */, const float* pe /* [L][C] */, float* pe_out /* or NULL: y + pe[l] */, float* mean, float* rstd,
+                   void* hip_stream);
 int dhw_op_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, long long pstride, int B, int L, int C,
                        float* dx, int accumulate, float* dgamma, float* dbeta, void* hip_stream);
 int dhw_op_layernorm(const float* x, long long rows, int C, float* y, float* mean, float* rstd, void* hip_stream);

@@ -124,7 +124,7 @@ def test_elementwise_norm_and_resampling_ops():
 def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
     """``addend`` of linear / conv3 (dhw_gemm_desc.addend), film_cols and ln_film_cols: y = op(x) + r, d r = d y, with fan-in on r
     (model.py:44-58 and cnn.py:87 chain exactly these), and ``silu_out`` (dhw_gemm_desc.act_out, act_out of dhw_op_ln_film): SiLU(y) as
-    a second output of the same pass; sizes with edge tiles (scalar output path) and interior tiles (vector path)."""
+    a second output of the same pass, ``pe`` of ln_film_cols: y + PE[l] as a third; sizes with edge tiles (scalar output path) and interior tiles (vector path)."""
     g = torch.Generator().manual_seed(11)
     for B, L, Cin, Cout in ((2, 24, 64, 96), (4, 64, 128, 128)):
         R = B * L
@@ -135,13 +135,14 @@ def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
         b = torch.randn(Cout, generator=g, requires_grad=True)
         b3 = torch.randn(Cout, generator=g, requires_grad=True)
         table = torch.randn(B, 4 * Cout, generator=g, requires_grad=True)     # gamma | beta for the FiLM, gamma | beta for LN + FiLM
+        pe = tm.positional_encoding(L, Cout, 2.0)
 
         def build(t, x, r, W, W3, b, b3, table):
             h, ha = t.linear(x, W, b, addend=r, silu_out=True)                 # x W^T + b + r, and SiLU of it from the same pass
             h2, h2a = t.conv3(ha, W3, b3, L, addend=h, silu_out=True)          # both outputs of the Linear are consumed
             h3 = t.film_cols(h2a, table, 0, Cout, B, act=True, addend=r)       # second consumer of r: its gradient is a fan-in
-            y, ya = t.ln_film_cols(h3, table, 2 * Cout, 3 * Cout, B, addend=h2, silu_out=True)
-            return t.add(y, ya)
+            y, ya, yp = t.ln_film_cols(h3, table, 2 * Cout, 3 * Cout, B, addend=h2, silu_out=True, pe=pe.to(DEV))   # + SiLU(y), y + PE
+            return t.add(t.add(y, ya), yp)
 
         y, vs, dy = _run(build, (x, r, W, W3, b, b3, table))
         h = F.linear(x, W, b) + r
@@ -149,7 +150,7 @@ def test_residual_adds_fused_into_gemm_film_and_layernorm_passes():
         ga, be, ga2, be2 = (table[:, i * Cout:(i + 1) * Cout] for i in range(4))
         h3 = F.silu(F.silu(h2).view(B, L, Cout) * ga[:, None] + be[:, None]).reshape(R, Cout) + r
         yr = (F.layer_norm(h3, (Cout,), eps=1e-6).view(B, L, Cout) * ga2[:, None] + be2[:, None]).reshape(R, Cout) + h2
-        ref = yr + F.silu(yr)
+        ref = yr + F.silu(yr) + (yr.view(B, L, Cout) + pe[None]).reshape(R, Cout)
         ref.backward(dy)
         _close(y.d, ref)
         for v, t_ref in zip(vs, (x, r, W, W3, b, b3, table)):
