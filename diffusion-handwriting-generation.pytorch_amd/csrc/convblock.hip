@@ -416,6 +416,7 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
       m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
       m.VT = m.KT + 32 * tile_stride<T>(CO);
       m.VS = smem;
+      m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, CO, BM>());
       enc_a_body<T, CO, BM, 4>(nx.a, m, b, m0, rows_valid);   // (tile starts are multiples of BM - 2: even, not 8-aligned)
     }
   }
@@ -437,7 +438,7 @@ size_t lds_bytes(int Cin, int up_cin = 0) {
 template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
   size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
-  if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>());
+  if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>() + enc_a_param_bytes<T, CO>());
   if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32)) || (CH != 0) != (nx != nullptr)) return hipErrorInvalidValue;
   if (CIN && (p.Cin != CIN || (UPC && p.up_cin != up_skip_width<UPC>()))) return hipErrorInvalidValue;
   const int tiles = (p.L + BM - 3) / (BM - 2);

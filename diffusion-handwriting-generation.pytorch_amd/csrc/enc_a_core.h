@@ -59,7 +59,69 @@ struct EpiParams {
       bet[i] = (f32x4){0, 0, 0, 0};
     }
   }
+  // The same from a parameter block in LDS (ParamStage below): b / g / be point at the vectors' first channel.  The 16
+  // lanes of a lane group read the same 16 bytes (broadcast), the 4 groups consecutive 16-byte slots: one conflict-free
+  // ds_read_b128 per vector and channel tile instead of a 1-KiB-per-wave trip through the CU's L1 return path.
+  DHW_DEV void lds(const float* b, const float* g, const float* be, int n0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+      gam[i] = *reinterpret_cast<const f32x4*>(g + n0 + 16 * i);
+      bet[i] = *reinterpret_cast<const f32x4*>(be + n0 + 16 * i);
+    }
+  }
+  DHW_DEV void lds_bias(const float* b, int n0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bias[i] = *reinterpret_cast<const f32x4*>(b + n0 + 16 * i);
+  }
 };
+
+// Epilogue parameter vectors of a fused kernel, staged ONCE per workgroup into LDS.  Loaded per lane from global memory
+// (16 identical copies per wave: EpiParams::load) every vector costs each wave a full 1-KiB wave-instruction on the CU's
+// L1 return path (64 B/clk, shared by the 8 waves), the path the weight stream of the attention-level layers is bound
+// by: 9 of a stage's 45 vector-memory instructions per wave at d = 384 (profiles/r03_inst_mix.json).  Here
+// NS <= 8 vectors of W floats are fetched by two waves each (128 threads, one 16-byte piece per lane, W / 4 <= 128 pieces),
+// four vectors per pass; a wave's vector index is uniform, so the source pointer is chosen with scalar selects.
+// load() only requests (unconditional, clamped: no branch, no s_waitcnt vmcnt(0) at a join), store() writes the block
+// pl[slot * W + c]; the caller's next workgroup barrier publishes it.  512-thread workgroups.
+template <int NS>
+struct ParamStage {
+  static_assert(NS <= 8, "two passes of four vectors");
+  uint4 v0, v1;   // (named members and pointer arguments, no arrays: hipcc left small arrays of either kind in scratch memory)
+  template <int W>
+  DHW_DEV void load(int tid, const float* s0, const float* s1, const float* s2, const float* s3, const float* s4 = nullptr,
+                    const float* s5 = nullptr, const float* s6 = nullptr, const float* s7 = nullptr) {
+    static_assert(W % 4 == 0 && W / 4 <= 128, "vector width");
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127;
+    const int cc = c < W / 4 ? c : W / 4 - 1;
+    const float* a = grp == 0 ? s0 : grp == 1 ? s1 : grp == 2 ? s2 : s3;
+    v0 = *reinterpret_cast<const uint4*>(a + 4 * cc);
+    if constexpr (NS > 4) {
+      // (vectors past NS: the last real one is fetched again and not stored)
+      const float* l = NS == 5 ? s4 : NS == 6 ? s5 : NS == 7 ? s6 : s7;
+      const float* b = grp == 0 ? s4 : grp == 1 ? (NS > 5 ? s5 : l) : grp == 2 ? (NS > 6 ? s6 : l) : (NS > 7 ? s7 : l);
+      v1 = *reinterpret_cast<const uint4*>(b + 4 * cc);
+    }
+  }
+  template <int W>
+  DHW_DEV void store(float* pl, int tid) const {
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127;
+    // two unconditional-shaped stores of by-value copies (written as `if (..) *p0 = v0; if (..) *p1 = v1;` on the members hipcc
+    // turned the pair into ONE store of a run-time-indexed member, which pinned the struct to scratch memory)
+    const uint4 a = v0;
+    float* pa = pl + grp * W + 4 * c;
+    if (c < W / 4 && grp < NS) *reinterpret_cast<uint4*>(pa) = a;
+    if constexpr (NS > 4) {
+      const uint4 b = v1;
+      asm volatile("" ::: "memory");
+      if (c < W / 4 && grp + 4 < NS) *reinterpret_cast<uint4*>(pa + 4 * W) = b;
+    }
+  }
+};
+// enc_a's parameter block: [b_q1 | b_d1 | gamma1 | beta1 | b_qkv2 (3 vectors)], bf16 kernels only (the fp32 parity mode's
+// tiles leave no room at d = 384 and keep the per-lane loads)
+template <typename T> constexpr bool enc_plds() { return sizeof(T) == 2; }
+template <typename T, int DM> constexpr size_t enc_a_param_bytes() { return enc_plds<T>() ? (size_t)7 * DM * sizeof(float) : 0; }
 
 // LDS regions of the enc_a stages.  XR and QR are [BM][DM] tiles (row stride tile_stride(DM)); VS is the staging area of the
 // transposed v2 tile (DM rows of BM keys), free to overlay XR / QR; KT / VT hold one 32-key block of text keys / values.
@@ -70,6 +132,7 @@ struct EncALds {
   char* KT;
   char* VT;
   char* VS;
+  float* PL;    // parameter block (enc_a_param_bytes), bf16 kernels
 };
 template <typename T, int DM, int BM>
 constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + OPAD<T>); }   // (V^T row pad: attn_core.h)
@@ -116,10 +179,16 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   char* VT = m.VT;
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
+  constexpr bool PLDS = enc_plds<T>();
+  const float* PL = m.PL;   // [b_q1 | b_d1 | gamma1 | beta1 | b_qkv2 x 3], DM floats each
   {
     CopyRegs<UX> cx;
     CopyRegs<UK> ck;
     CopyRegs<UV> cv;
+    ParamStage<7> cp;
+    if constexpr (PLDS) {
+      cp.template load<DM>(tid, p.b_q1, p.b_d1, gam + p.f1, bet + p.f1, p.b_qkv2, p.b_qkv2 + DM, p.b_qkv2 + 2 * DM);
+    }
     const T* xs = reinterpret_cast<const T*>(p.x);
     if (p.x)
       cx.load(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
@@ -135,6 +204,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
              [&](int id) { return id / CPR < p.Lt; });
     cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
                 [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
+    if constexpr (PLDS) cp.template store<DM>(m.PL, tid);
   }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
   PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
@@ -143,7 +213,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane);
-    ep.load_bias(p.b_q1, n0);
+    if constexpr (!PLDS) ep.load_bias(p.b_q1, n0);
   }
   lds_barrier();
   ENC_STAMP(1);
@@ -159,6 +229,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
         pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_q1 + (unsigned)((m0 + row0 + j * 16 + l15) * DM + n0 + 16 * i));
     ring.template run_s<MT, KC>(acc, xop, S, KC);
     ENC_STAMP(8);
+    if constexpr (PLDS) ep.lds_bias(PL, n0);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -213,7 +284,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   }
   if (act) {
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);   // in flight across the barrier
-    ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
+    if constexpr (!PLDS) ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
   }
   lds_barrier();
   ENC_STAMP(3);
@@ -225,6 +296,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
       ring.template run_s<MT, KC>(acc, qop, S, KC);
       ENC_STAMP(10);
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
+      if constexpr (PLDS) ep.lds(PL + DM, PL + 2 * DM, PL + 3 * DM, n0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -258,7 +330,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
     acc_zero(acc);
     f32x4 pb[NT][MT];
     if (act) {
-      ep.load_bias(p.b_qkv2 + chunk * DM, n0 + opaque);
+      if constexpr (!PLDS) ep.load_bias(p.b_qkv2 + chunk * DM, n0 + opaque);
       if (chunk < 2) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -268,6 +340,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
       }
       ring.template run_s<MT, KC>(acc, xop + opaque, S, KC);
       ENC_STAMP(12 + chunk);
+      if constexpr (PLDS) ep.lds_bias(PL + (4 + chunk) * DM, n0 + opaque);
       if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane);
     }
     if (chunk < 2 && MT == 1) {

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
   m.VT = m.KT + 32 * tile_stride<T>(DM);
   m.VS = smem;   // spans the x2 and q1 tiles: DM * (BM * ES + 16) <= 2 * BM * S
+  m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DM, BM>());
   enc_a_body<T, DM, BM>(p, m, b, m0, min(BM, p.Lk - m0));
 }
 
@@ -56,17 +57,26 @@ constexpr bool self_db() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64
 template <typename T, int DM, int BM>
 constexpr int self_vpad() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, self_db<T, DM, BM>() ? 2 : 1, 32) <= 160 * 1024 ? 32 : 16; }
 template <typename T, int DM, int BM>
-constexpr size_t lds_bc_bytes() {
+constexpr size_t lds_bc_tiles() {
   constexpr size_t S = tile_stride<T>(DM);
   constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = self_att_bytes<T, DM, BM>(self_kbs<T, DM, BM>(), self_db<T, DM, BM>() ? 2 : 1, self_vpad<T, DM, BM>());
   return stages > att ? stages : att;
 }
+// enc_bc's parameter block (bf16 kernels): [b_d2 | gamma2 | beta2 | b_f1 (2 vectors) | b_f2 | gamma3 | beta3].  It sits behind
+// the tiles when that fits the 160 KiB; the double-buffered d = 256 variants have 3 KB to spare, there the block is written
+// after the last key block into the staging buffer that block does NOT use (free since the previous iteration's barrier).
+template <typename T, int DM> constexpr size_t enc_bc_param_bytes() { return enc_plds<T>() ? (size_t)8 * DM * sizeof(float) : 0; }
+template <typename T, int DM, int BM>
+constexpr bool bc_params_fixed() { return lds_bc_tiles<T, DM, BM>() + enc_bc_param_bytes<T, DM>() <= 160 * 1024; }
+template <typename T, int DM, int BM>
+constexpr size_t lds_bc_bytes() { return lds_bc_tiles<T, DM, BM>() + (bc_params_fixed<T, DM, BM>() ? enc_bc_param_bytes<T, DM>() : 0); }
 
 // NEXT: 0, or the EncChain mode compiled into this variant (DN = width of the chained layer)
 template <typename T, int DM, int BM, int NEXT>
 constexpr size_t lds_bc_chain_bytes() {
   constexpr size_t S = tile_stride<T>(DM), base = 3 * BM * S + 2 * 8 * BM * sizeof(float);
-  constexpr size_t chain = NEXT == 1 ? base + enc_a_text_kv_bytes<T, DM, BM>() : NEXT == 2 ? base + enc_a_text_kv_bytes<T, 384, BM / 2>() : 0;
+  constexpr size_t chain = NEXT == 1 ? base + enc_a_text_kv_bytes<T, DM, BM>() + enc_a_param_bytes<T, DM>()
+                         : NEXT == 2 ? base + enc_a_text_kv_bytes<T, 384, BM / 2>() + enc_a_param_bytes<T, 384>() : 0;
   return chain > lds_bc_bytes<T, DM, BM>() ? chain : lds_bc_bytes<T, DM, BM>();
 }
 
@@ -99,6 +109,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   WRing<T, NT, RING> ring;
   EpiParams<NT> ep;
+  constexpr bool PLDS = enc_plds<T>(), PLFIX = bc_params_fixed<T, DM, BM>();
+  float* PL = reinterpret_cast<float*>(smem + lds_bc_tiles<T, DM, BM>());   // (PLFIX; else chosen behind the attention loop)
+  ParamStage<8> cp;
+  // (a macro, not a lambda: with `cp` captured by a closure hipcc kept it in scratch memory)
+#define BC_PARAMS_REQUEST() cp.template load<DM>(tid, p.b_d2, gam + p.f2, bet + p.f2, p.b_f1, p.b_f1 + DM, p.b_f2, gam + p.f3, bet + p.f3)
   STAMP(16);
   DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 40, __builtin_amdgcn_s_memtime());
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
@@ -142,7 +157,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
     }
+    if constexpr (PLDS) BC_PARAMS_REQUEST();   // (!PLFIX: held in registers across the key blocks, 8 VGPRs)
     request(0);   // (one round trip together with the q fragments)
+    if constexpr (PLDS && PLFIX) cp.template store<DM>(PL, tid);
     commit(0, R2, R2 + KBS * SK);
     lds_barrier();
     int ib = 0;
@@ -165,6 +182,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       // (after the last block the barrier behind the a2 store below separates the staging tiles from their next use)
     }
+    if constexpr (PLDS && !PLFIX) {
+      // the last block (index ib - 1) was read from buffer (ib - 1) & 1; the other one is free: its readers finished an
+      // iteration ago, behind a barrier.  In buffer 0 the block goes behind the stage tiles and the LayerNorm scratch.
+      static_assert(DB, "a single staging buffer leaves room for a fixed parameter block");
+      static_assert((size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_bc_param_bytes<T, DM>() <= (size_t)BUFB, "parameter block inside buffer 0");
+      PL = reinterpret_cast<float*>(((ib - 1) & 1) ? R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float) : R2 + BUFB);
+      cp.template store<DM>(PL, tid);
+    }
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
@@ -178,9 +203,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+  else if constexpr (PLDS) {   // (diagnostic path without the attention stage)
+    BC_PARAMS_REQUEST();
+    if constexpr (!PLFIX) PL = reinterpret_cast<float*>(R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float));
+    cp.template store<DM>(PL, tid);
+  }
   if (act) {
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
-    ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
+    if constexpr (!PLDS) ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
   }
   lds_barrier();
   STAMP(17);
@@ -202,6 +232,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       ring.template run_s<MT, KC>(acc, op1, S, KC);
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+      if constexpr (PLDS) ep.lds(PL, PL + DM, PL + 2 * DM, n0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -234,8 +265,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (act) {
       f32x4 acc[NT][MT];
       acc_zero(acc);
-      ep.load_bias(p.b_f1 + hh * DM, n0);
+      if constexpr (!PLDS) ep.load_bias(p.b_f1 + hh * DM, n0);
       ring.template run_s<MT, KC>(acc, op1, S, KC);
+      if constexpr (PLDS) ep.lds_bias(PL + (3 + hh) * DM, n0);
       // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
 #pragma unroll
@@ -258,7 +290,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     STAMP(21 + 2 * hh);
   }
   if (act) {
-    ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
+    if constexpr (PLDS) ep.lds(PL + 5 * DM, PL + 6 * DM, PL + 7 * DM, n0);
+    else ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -289,6 +322,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
     m.VT = m.KT + 32 * tile_stride<T>(DM);
     m.VS = R1;
+    m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DM, BM>());
     enc_a_body<T, DM, BM>(nx.a, m, b, m0, rows_valid);
   } else if constexpr (NEXT == 2) {
     // AvgPool1d(2) of the out tile -> R1; Linear DM -> DN (att_dense) -> x tile of the first attention layer; its enc_a
@@ -332,6 +366,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
     m.VT = m.KT + 32 * tile_stride<T>(DN);
     m.VS = XN;
+    m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DN, BN2>());
     enc_a_body<T, DN, BN2>(nx.a, m, b, m02, rows2);
   }
 }
@@ -352,7 +387,7 @@ constexpr bool has_chain(int mode) {   // (LDS: the chained layer's text K/V blo
 }
 
 template <typename T, int DM, int BM>
-constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, DM, BM>(); }
+constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, DM, BM>() + enc_a_param_bytes<T, DM>(); }
 // does the (element type, width, row tile) combination fit the 160 KiB of LDS in both halves of the layer?
 template <typename T, int DM, int BM>
 constexpr bool fits() { return lds_a_bytes<T, DM, BM>() <= 160 * 1024 && lds_bc_bytes<T, DM, BM>() <= 160 * 1024 && (DM % 128 == 0 || BM >= 32); }
