@@ -22,6 +22,13 @@ namespace {
 
 
 #define STAMP(slot) ENC_STAMP(slot)
+// per-wave stamps of enc_bc (diagnostic builds, tools/bench_encw.cpp): shader-clock time of every wave of workgroup 0 at the
+// phase boundaries inside the stages -> p.stamps[64 + wave * 32 + slot]
+#ifdef DHW_STAMPS
+#define WST(slot) do { if (p.stamps && blockIdx.x == 0 && lane == 0) p.stamps[64 + wave * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WST(slot) do { } while (0)
+#endif
 
 template <typename T, int DM, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc_a_kernel(const EncLayerParams p) {
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (a macro, not a lambda: with `cp` captured by a closure hipcc kept it in scratch memory)
 #define BC_PARAMS_REQUEST() cp.template load<DM>(tid, p.b_d2, gam + p.f2, bet + p.f2, p.b_f1, p.b_f1 + DM, p.b_f2, gam + p.f3, bet + p.f3)
   STAMP(16);
+  WST(0);
   DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 40, __builtin_amdgcn_s_memtime());
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       PL = reinterpret_cast<float*>(((ib - 1) & 1) ? R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float) : R2 + BUFB);
       cp.template store<DM>(PL, tid);
     }
+    WST(1);
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
@@ -212,7 +221,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
     if constexpr (!PLDS) ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
   }
+  WST(2);
   lds_barrier();
+  WST(3);
   STAMP(17);
 
   {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
@@ -231,7 +242,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           res[i][j] = load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i));
         }
       ring.template run_s<MT, KC>(acc, op1, S, KC);
+      WST(4);
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+      WST(5);
       if constexpr (PLDS) ep.lds(PL, PL + DM, PL + 2 * DM, n0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -239,7 +252,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
     }
     STAMP(18);
+    WST(6);
     ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    WST(7);
     if (act) {
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -254,7 +269,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
   }
+  WST(8);
   lds_barrier();
+  WST(9);
   STAMP(19);
 
   // ---- out = FiLM3(LN(W2 SiLU(W1 SiLU(x3) + b1) + b2 + x3)); the 2*DM hidden layer is processed in two halves
@@ -267,9 +284,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       acc_zero(acc);
       if constexpr (!PLDS) ep.load_bias(p.b_f1 + hh * DM, n0);
       ring.template run_s<MT, KC>(acc, op1, S, KC);
+      WST(10 + 6 * hh);
       if constexpr (PLDS) ep.lds_bias(PL + (3 + hh) * DM, n0);
       // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
       ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
+      WST(11 + 6 * hh);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -280,13 +299,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v);
         }
     }
+    WST(12 + 6 * hh);
     lds_barrier();
+    WST(13 + 6 * hh);
     STAMP(20 + 2 * hh);
     if (act) {
       ring.template run_s<MT, KC>(acc2, op3, S, KC);
+      WST(14 + 6 * hh);
       if (hh == 0) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // FFN half 1
     }
     if (hh == 0) lds_barrier();   // R3 is rewritten by the next half (after the last one the LayerNorm barrier below does)
+    WST(15 + 6 * hh);
     STAMP(21 + 2 * hh);
   }
   if (act) {
@@ -298,7 +321,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < MT; ++j)
         acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
   }
+  WST(22);
   ln_rows<T, MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
+  WST(23);
   // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
   if (act) {
 #pragma unroll
@@ -313,6 +338,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.pool)
     tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);
+  WST(24);
   DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 41, __builtin_amdgcn_s_memtime());
 
   if constexpr (NEXT == 1) {

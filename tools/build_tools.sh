@@ -19,6 +19,7 @@ $H -c tools/bench_conv.cpp -o tools/bin/bench_conv.o && hipcc --offload-arch=gfx
 $H -c tools/bench_enc.cpp -o tools/bin/bench_enc.o && hipcc --offload-arch=gfx950 tools/bin/bench_enc.o $P/enclayer.o -o tools/bin/bench_enc
 $H -c tools/bench_sgemm.cpp -o tools/bin/bench_sgemm.o && hipcc --offload-arch=gfx950 tools/bin/bench_sgemm.o $P/train.o -o tools/bin/bench_sgemm
 $H -c tools/bench_text.cpp -o tools/bin/bench_text.o && hipcc --offload-arch=gfx950 tools/bin/bench_text.o $P/gemm.o -o tools/bin/bench_text
+$H -c tools/bench_encw.cpp -o tools/bin/bench_encw.o && hipcc --offload-arch=gfx950 tools/bin/bench_encw.o $P/enclayer.o -o tools/bin/bench_encw
 for t in bench_l2 bench_copy bench_handoff bench_lat; do $H tools/$t.cpp -o tools/bin/$t; done
 echo "built: $(ls tools/bin | grep -v '\.o$' | tr '\n' ' ')"
 # ablation builds of the ConvBlock bench (diagnostics; DHW_ABL bit mask, see csrc/convblock.hip): tools/bin/bench_conv_abl<N>
