@@ -473,7 +473,7 @@ def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd", "csrc")
-    sampler = {"convblock.hip", "enclayer.hip", "gemm.hip", "attn.hip", "misc.hip", "textside.hip", "enc_a_core.h", "enc16_core.h", "attn_core.h",
+    sampler = {"convblock.hip", "enclayer.hip", "gemm.hip", "attn.hip", "misc.hip", "textside.hip", "enc_a_core.h", "enc_bc_core.h", "convblock_core.h", "attn_core.h",
                "gemm_core.h", "epilogue.h", "heads_core.h", "dhw_common.h", "xcd_swizzle.h",   # the kernels' translation units and the headers only they include
                "dhw_api.cpp"}                                                                 # ... and the host side that picks launch variants and chains
     for f in sorted(os.listdir(d)):

@@ -66,6 +66,8 @@ SIGNATURES = {
     "dhw_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dhw_set_graph": (C.c_int, [_P, C.c_int]),
+    "dhw_debug_persist_plans": (C.c_int, [_P]),
+    "dhw_debug_persist_trace": (C.c_int, [_P, _P, C.c_int64]),
     "dhw_debug_set_teacher": (C.c_int, [_P, _P, _P, C.c_int]),
     "dhw_debug_xcd_swizzle": (C.c_int, [C.c_int, C.c_int]),
     "dhw_set_streams": (C.c_int, [_P, C.c_int]),

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdhw_hip.so")
-SOURCES = ["gemm.hip", "convblock.hip", "enclayer.hip", "attn.hip", "misc.hip", "style.hip", "textside.hip", "train.hip", "dhw_api.cpp", "dhw_style_api.cpp", "dhw_train_api.cpp"]
+SOURCES = ["gemm.hip", "convblock.hip", "enclayer.hip", "persist.hip", "attn.hip", "misc.hip", "style.hip", "textside.hip", "train.hip", "dhw_api.cpp", "dhw_style_api.cpp", "dhw_train_api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

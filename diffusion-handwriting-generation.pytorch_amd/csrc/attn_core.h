@@ -122,10 +122,10 @@ DHW_DEV void attn_wave16_auto(const Frag<T> (&qf)[(D + 31) / 32], const T* krow,
 //   padbits: bit 4t+r set = this lane's key kb + 16t + 4*(lane>>4) + r is a padded text token (score += -1e9); the caller
 //            reads the mask ahead of time (attn_pad_bits) so no global load sits in the softmax
 template <typename T, int D, int KB>
-DHW_DEV void attn_block_lds(const Frag<T> (&qf)[(D + 31) / 32], const char* kt, int SK, const char* vt, int SV, int kb,
+DHW_DEV void attn_block_lds(int lane, const Frag<T> (&qf)[(D + 31) / 32], const char* kt, int SK, const char* vt, int SV, int kb,
                             unsigned padbits, int Lk, float& m_run, float& l_run, f32x4 (&o)[D / 16]) {
   constexpr int ES = sizeof(T), DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
-  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int g = lane >> 4;
   const float scale = rsqrtf((float)D);
   f32x4 s[NTILE];
 #pragma unroll
@@ -215,7 +215,7 @@ template <typename T> DHW_DEV void vt_store_piece(char* row, int part, const uin
 #define DHW_ATT_ABL 0   // diagnostic builds only: bit0 = no MFMAs, bit1 = no exponentials, bit2 = no LDS operand reads, bit3 = no max / rescale
 #endif
 template <int D, int KB, bool MASKED, int NU, bool TAIL>
-DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char* const (&kt)[NU], int SK, const char* const (&vt)[NU], int SV, int kb,
+DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], const char* const (&kt)[NU], int SK, const char* const (&vt)[NU], int SV, int kb,
                              unsigned padbits, int Lk, float (&m_run)[NU], float (&l_run)[NU], f32x4 (*o)[D / 16]) {
   // No implicit fma contraction in here: with nothing between them (TAIL = false) hipcc fused `u = s * c` and `u - m` into
   // fma(s, c, -m) — the non-robust form described above (NaN in the long-schedule stress test) — while the TAIL = true copy,
@@ -224,7 +224,7 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
   typedef bf16_t T;
   constexpr int DT = D / 16, KCH = (D + 31) / 32, NTILE = KB / 16, NPF = KB / 32;
   static_assert(D % 32 == 0, "head width");
-  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int g = lane >> 4;
   const float c = rsqrtf((float)D) * 1.4426950408889634f;
   f32x4 s[NU][NTILE];
 #pragma unroll
@@ -319,7 +319,7 @@ DHW_DEV void attn_block_bf16(const Frag<bf16_t> (*qf)[(D + 31) / 32], const char
 // second unit of a wave may not).  kt0 / vt0: this lane's LDS row addresses for head 0 (K tile row lane & 15; V^T tile row
 // lane & 15); head h lies h * 64 channels further in both tiles.
 template <typename T, int KB, bool MASKED, int UMAX>
-DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, const char* vt0, int SV, int hs, int HS, int H, int kb,
+DHW_DEV void attn_units(int lane, const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, const char* vt0, int SV, int hs, int HS, int H, int kb,
                         unsigned padbits, int Lk, float (&mr)[UMAX], float (&lr)[UMAX], f32x4 (&o)[UMAX][4]) {
   constexpr int ES = sizeof(T);
   if constexpr (sizeof(T) == 2) {
@@ -332,8 +332,8 @@ DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, c
         const char* const kt[1] = {kt0 + h * 64 * ES};
         const char* const vt[1] = {vt0 + h * 64 * SV};
         float m1[1] = {mr[u]}, l1[1] = {lr[u]};
-        if (kb + KB > Lk) attn_block_bf16<64, KB, MASKED, 1, true>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
-        else attn_block_bf16<64, KB, MASKED, 1, false>(qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        if (kb + KB > Lk) attn_block_bf16<64, KB, MASKED, 1, true>(lane, qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        else attn_block_bf16<64, KB, MASKED, 1, false>(lane, qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
         mr[u] = m1[0]; lr[u] = l1[0];
       }
     }
@@ -341,7 +341,7 @@ DHW_DEV void attn_units(const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, c
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
-      if (h < H) attn_block_lds<T, 64, KB>(qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV + 4 * ((threadIdx.x & 63) >> 4) * ES, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
+      if (h < H) attn_block_lds<T, 64, KB>(lane, qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV + 4 * (lane >> 4) * ES, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
     }
   }
 }
@@ -355,8 +355,8 @@ struct PadMask {
   // Unconditional loads at a clamped index: a per-lane `key < Lk ? trow[key] : 1` compiles to one branch per token with
   // s_waitcnt vmcnt(0) inside — eight dependent memory round trips at the top of every enc_a (r2, .s) — while keys at or
   // past Lk are masked by attn_block_lds itself, so their bits may hold anything.
-  DHW_DEV void load(const int64_t* trow, int kb, int Lk) {
-    const int g = (threadIdx.x & 63) >> 4;
+  DHW_DEV void load(int lane, const int64_t* trow, int kb, int Lk) {
+    const int g = lane >> 4;
     if (!trow) {   // (wave-uniform)
 #pragma unroll
       for (int i = 0; i < KB / 4; ++i) tok[i] = 1;

@@ -21,6 +21,7 @@
 #include "xcd_swizzle.h"
 #include "../../include/dhw_debug.h"
 #include "dhw_kernels.h"
+#include "persist.h"
 
 namespace {
 
@@ -223,6 +224,20 @@ struct dhw_handle {
   float* d_noise_stage = nullptr;
   size_t noise_stage_cap = 0;
   uint64_t* d_seed = nullptr;   // [seed, first_sample] read by the noise kernels
+
+  // One persistent launch per denoiser call inside dhw_sample's graph (persist.h): env DHW_PERSIST=1.  OFF by default: measured
+  // 359 us per call against 328 us for the eleven launches (profiles/r04_persistent_step_trace.log) — bit-identical
+  // samples, but every hand-off costs what a kernel boundary costs and the merged kernel's bodies compile worse.  One StepPlan
+  // per sampler step, built by running the launch sequence in record mode, keyed like the graphs.
+  bool persist = false;
+  int persist_grid = 0;               // resident workgroups to start = the device's CU count
+  unsigned* d_step_sync = nullptr;    // tickets / per-sample counters (zero between launches)
+  size_t step_sync_words = 0;
+  unsigned* h_step_err = nullptr;     // host-mapped error word of the step kernels (bounded spins), and its device address
+  unsigned* d_step_err = nullptr;
+  struct StepPlans { StepPlan* dev = nullptr; bool ok = false; };
+  unsigned long long* d_step_trace = nullptr;   // diagnostics (DHW_PERSIST_TRACE=1): [workgroup][phase][4] stamps of the LAST step of a call
+  std::map<std::vector<uint64_t>, StepPlans> plans;
 
   int last_B = 0, last_L = 0, last_Lt = 0;
 };
@@ -537,7 +552,25 @@ struct Ctx {
   bool fuse_input = false;  // enc1 evaluates input_dense while staging (sampling loop); forward() keeps the tap
   bool use_plane = false;   // stroke path reads the text K/V of step `plane_step` from the plane
   long plane_step = 0;
+  // record mode (persist.h): the fused launches of stroke_path are appended to `rec` as phases instead of being launched;
+  // anything the persistent kernel has no phase for sets rec_fail
+  std::vector<StepPhase>* rec = nullptr;
+  bool rec_fail = false;
 };
+
+// append one phase of the persistent per-step kernel (record mode)
+void rec_phase(Ctx& c, int kind, int L, const ConvBlockParams* cb, const EncLayerParams* el, const EncChain* nx) {
+  int rows = 0, lv = 0;
+  if (!step_kind_geometry(kind, L, &rows, &lv) || (int)c.rec->size() >= STEP_MAX_PHASES) { c.rec_fail = true; return; }
+  StepPhase ph{};
+  ph.kind = kind;
+  ph.rows = rows;
+  ph.tps = (lv + rows - 1) / rows;
+  if (cb) ph.cb = *cb;
+  if (el) ph.el = *el;
+  if (nx) ph.nx = *nx;
+  c.rec->push_back(ph);
+}
 
 void* BUF(const Ctx& c, const std::string& n) { return c.ws->buf.at(n); }
 
@@ -586,12 +619,14 @@ double gemm_bytes(const dhw_handle* h, const GemmParams& p) {   // algorithmic: 
   return b;
 }
 void run_gemm(Ctx& c, const char* label, const GemmParams& p) {
+  if (c.rec) { c.rec_fail = true; return; }
   if (c.err) return;
   Launch l(c.h, c.st, label, gemm_flops(p), gemm_bytes(c.h, p));
   hipError_t e = launch_gemm(c.h->prec, p, c.st);
   if (e != hipSuccess) c.err = fail(c.h, DHW_ERR_HIP, "gemm %s: %s", label, hipGetErrorString(e));
 }
 void run_attn(Ctx& c, const char* label, const AttnParams& p) {
+  if (c.rec) { c.rec_fail = true; return; }
   if (c.err) return;
   Launch l(c.h, c.st, label, 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.D,
            (double)p.B * p.H * p.D * (2.0 * p.Lq + 2.0 * p.Lk) * c.h->es);
@@ -600,7 +635,8 @@ void run_attn(Ctx& c, const char* label, const AttnParams& p) {
 }
 #define RUN_SMALL(c, label, call)                                                                  \
   do {                                                                                             \
-    if (!(c).err) {                                                                                \
+    if ((c).rec) (c).rec_fail = true;                                                              \
+    else if (!(c).err) {                                                                                \
       Launch l_((c).h, (c).st, label);                                                             \
       hipError_t e_ = (call);                                                                      \
       if (e_ != hipSuccess) (c).err = fail((c).h, DHW_ERR_HIP, "%s: %s", label, hipGetErrorString(e_)); \
@@ -638,6 +674,21 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
       q.hp.L = L;
       q.out = nullptr;   // the fp32 activation never leaves LDS
     }
+    if (c.rec) {
+      // the phase kinds the persistent kernel is built with (persist.h): the reference's widths, the canonical row tiles
+      const bool ch = chain && chain->mode == 1 && convblock_chain_supported(h->prec, q, *chain);
+      if (chained) *chained = ch;
+      int kind = -1;
+      if (n == "enc1" && strokes && !up) kind = PK_CONV_ENC1;
+      else if (n == "enc2" && ch && !up && !strokes) kind = PK_CONV_ENC2A;
+      else if (n == "enc4" && !(chain && chain->mode) && !up && !strokes) kind = PK_CONV_ENC4;
+      else if (n == "dec3" && up) kind = PK_CONV_DEC3;
+      else if (n == "dec2" && up) kind = PK_CONV_DEC2;
+      else if (n == "dec1" && up && q.fuse_heads) kind = PK_CONV_DEC1;
+      if (kind < 0 || h->prec != PREC_BF16 || (L & 1)) { c.rec_fail = true; return; }
+      rec_phase(c, kind, c.L, &q, nullptr, ch ? chain : nullptr);
+      return;
+    }
     if (!c.err) {
       const double rows = (double)c.B * L;
       const double upf = up ? 3.0 * up->cin * w.cin : 0.0;   // skip_conv MACs per row
@@ -654,6 +705,7 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     tap(c, n, n, L, w.cout, out_f32);
     return;
   }
+  if (c.rec) { c.rec_fail = true; return; }
   {  // h1 = SiLU(FiLM1(conv1(SiLU(x))))
     GemmParams p = gp_base(c, L, w.cout / 2);
     p.seg[0] = GemmSeg{x, w.w_c1, w.cin, 3, 1};
@@ -756,6 +808,22 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
     EncLayerParams q = enc_params(c, n, w, x, Lk, lpad, text, pool);
     q.bm_min = bm_min;
     const double rows = (double)c.B * Lk, dd = d;
+    if (c.rec) {
+      const bool chained = chain && chain->mode;
+      if (h->prec != PREC_BF16) { c.rec_fail = true; return; }
+      if (!skip_a) {
+        if (d == 256) rec_phase(c, PK_A256, c.L, nullptr, &q, nullptr);
+        else c.rec_fail = true;
+      }
+      int kind = -1;
+      if (d == 192 && !chained && skip_a) kind = PK_BC192;
+      else if (d == 256 && chained && chain->mode == 2 && !skip_a && bm_min == 32 && !(Lk & 1)) kind = PK_BC256_N2;
+      else if (d == 384 && chained && chain->mode == 1 && skip_a) kind = PK_BC384_N1;
+      else if (d == 384 && !chained && skip_a) kind = PK_BC384;
+      if (kind < 0) { c.rec_fail = true; return; }
+      rec_phase(c, kind, c.L, nullptr, &q, chained ? chain : nullptr);
+      return;
+    }
     for (int which = skip_a ? 1 : 0; which < 2 && !c.err; ++which) {
       double fl = which == 0 ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd
                              : 2.0 * rows * dd * dd * 5 + 4.0 * rows * Lk * dd;
@@ -774,6 +842,7 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
     tap(c, n, n, Lk, d);
     return;
   }
+  if (c.rec) { c.rec_fail = true; return; }
   {  // q1 = Wq(x + PE)
     GemmParams p = gp_base(c, Lk, d);
     p.seg[0] = GemmSeg{x, w.w_q1, d, 1, 0};
@@ -1179,6 +1248,17 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
   if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
   if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
+  if (const char* e = getenv("DHW_PERSIST")) h->persist = atoi(e) != 0;
+  if (!rc && h->prec == PREC_BF16 && h->persist) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || persist_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "persistent kernel setup failed: %s", hipGetErrorString(hipGetLastError()));
+    else {
+      h->persist_grid = prop.multiProcessorCount;
+      if (hipHostMalloc((void**)&h->h_step_err, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&h->d_step_err, h->h_step_err, 0) != hipSuccess)
+        rc = fail(h, DHW_ERR_HIP, "host-mapped error word: %s", hipGetErrorString(hipGetLastError()));
+      else *h->h_step_err = 0;
+    }
+  }
   if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && textside_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1197,6 +1277,7 @@ void dhw_destroy(dhw_handle* h) {
   for (int i = 1; i < MAX_STREAMS; ++i)
     if (h->sub_streams[i]) hipStreamDestroy(h->sub_streams[i]);
   for (void* p : h->allocs) hipFree(p);
+  if (h->h_step_err) hipHostFree(h->h_step_err);
   delete h;
 }
 
@@ -1347,9 +1428,12 @@ int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const 
 static int plane_chunk(int T) { return std::min(T, 64); }
 
 // One prompt sub-batch [b0, b0+Bs) of a B-prompt batch, enqueued on `st` with workspace `w`.
+// d_plans: device array of T StepPlans (persist.h) -> every denoiser call is ONE persistent launch; rec_out: record mode —
+// nothing is launched, the T plans are built on the host (rec_out->size() != T afterwards: this shape has no persistent form).
 static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, const int64_t* text, const float* style,
                           int L, int Lt, int T, int mode, const float* noise, float* out, hipStream_t st,
-                          const std::vector<float>& beta, const std::vector<float>& alpha) {
+                          const std::vector<float>& beta, const std::vector<float>& alpha, const StepPlan* d_plans = nullptr,
+                          std::vector<StepPlan>* rec_out = nullptr) {
   const long rows = (long)Bs * L;
   const size_t step_stride = (size_t)B * L * 2;   // one noise draw for the whole batch
   text += (size_t)b0 * Lt;
@@ -1359,23 +1443,24 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
   Ctx c{h, w, st, Bs, L, Lt, h->dims.S * 5, h->d_film_T, 0};
   c.fuse_input = true;
   // x_T
-  if (noise) {
+  if (rec_out) {
+  } else if (noise) {
     hipError_t e = hipMemcpyAsync(w->d_xt, noise, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy x_T: %s", hipGetErrorString(e));
   } else {
     RUN_SMALL(c, "randn_init", launch_randn_init(w->d_xt, rows, L, h->d_seed, b0, st));
   }
-  text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
+  if (!rec_out) text_style_static(c, text, style);   // sigma-independent: once per sample batch, not per step
   const int TC = plane_chunk(T);
   for (int step = 0, i = T - 1; i >= 0; --i, ++step) {
-    if (h->teach_every > 0 && step > 0 && step % h->teach_every == 0) {
+    if (!rec_out && h->teach_every > 0 && step > 0 && step % h->teach_every == 0) {
       // teacher forcing (tests only): x after `step` steps -> capture[k], x := reset[k]
       const size_t k = (size_t)(step / h->teach_every - 1), off = (k * B + b0) * (size_t)L * 2;
       hipError_t e = hipMemcpyAsync(h->teach_capture + off, w->d_xt, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
       if (e == hipSuccess) e = hipMemcpyAsync(w->d_xt, h->teach_reset + off, rows * 2 * 4, hipMemcpyDeviceToDevice, st);
       if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "teacher copy: %s", hipGetErrorString(e));
     }
-    if (h->plane && step % TC == 0) {
+    if (!rec_out && h->plane && step % TC == 0) {
       // The text side (TextStyleEncoder + every layer's text K/V, text_style.py:91-104, model.py:38-42) depends on
       // (text, style, sigma_i) only and the sigma schedule is known: evaluate it for the next `ns` steps in ONE
       // batched pass (ns*Bs "samples", FiLM row per step) instead of 16 small launches inside every step.
@@ -1393,7 +1478,10 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
     c.film = h->d_film_T + (size_t)i * 2 * h->film_tot;
     c.use_plane = h->plane;
     c.plane_step = step % TC;
-    if (!h->plane) text_style_dynamic(c);
+    if (!h->plane) {
+      if (rec_out) return 0;   // (the persistent form reads the text K/V from the all-steps plane)
+      text_style_dynamic(c);
+    }
     HeadsParams hp{};
     hp.eps = nullptr;
     hp.pen = nullptr;
@@ -1419,6 +1507,30 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
     if (i == 0) hp.out3 = out;
     const bool fh = h->fuse && h->fuse_heads;
     c.fhp = fh ? &hp : nullptr;
+    if (rec_out) {
+      if (!fh) return 0;
+      std::vector<StepPhase> phases;
+      c.rec = &phases;
+      c.rec_fail = false;
+      stroke_path(c, w->d_xt, text);
+      c.rec = nullptr;
+      if (c.rec_fail || c.err || phases.empty()) return c.err;
+      StepPlan sp{};
+      sp.nphase = (int)phases.size();
+      sp.B = Bs;
+      sp.spx = (Bs + STEP_XCDS - 1) / STEP_XCDS;
+      sp.sync = h->d_step_sync;
+      sp.err = h->d_step_err;
+      for (size_t k = 0; k < phases.size(); ++k) { sp.ph[k] = phases[k]; sp.cum_tps[k + 1] = sp.cum_tps[k] + phases[k].tps; }
+      rec_out->push_back(sp);
+      continue;
+    }
+    if (d_plans) {
+      Launch l(h, st, "step.persistent");
+      hipError_t e = launch_step(d_plans + step, h->persist_grid, st);
+      if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "persistent step %d: %s", step, hipGetErrorString(e));
+      continue;
+    }
     stroke_path(c, w->d_xt, text);
     if (!fh) launch_heads_for(c, hp);
     if (c.err) return c.err;
@@ -1426,17 +1538,44 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
   return c.err;
 }
 
+// The StepPlans of one dhw_sample shape (cached like the graphs): built by running the enqueue in record mode, uploaded once.
+// Returns null when this shape / configuration has no persistent form (the caller then launches kernel by kernel).
+static const StepPlan* ensure_step_plans(dhw_handle* h, const std::vector<uint64_t>& key, int B, int L, int Lt, int T, int mode,
+                                         const float* noise, const std::vector<float>& beta, const std::vector<float>& alpha) {
+  if (!h->persist || h->nstreams != 1 || h->prec != PREC_BF16 || !h->fuse || !h->plane || !h->fuse_heads || !h->fuse_up || !h->chain) return nullptr;
+  auto it = h->plans.find(key);
+  if (it != h->plans.end()) return it->second.ok ? it->second.dev : nullptr;
+  dhw_handle::StepPlans& sp = h->plans[key];
+  const size_t need = step_sync_words(B);
+  if (need > h->step_sync_words) {   // (earlier plans keep the smaller buffer: it is never freed before destroy)
+    if (dev_alloc(h, (void**)&h->d_step_sync, need * sizeof(unsigned))) return nullptr;
+    h->step_sync_words = need;
+  }
+  std::vector<StepPlan> host;
+  if (sample_enqueue(h, &h->ws[0], 0, B, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, noise, h->d_out_stage, nullptr, beta, alpha, nullptr, &host) ||
+      (int)host.size() != T)
+    return nullptr;
+  if (getenv("DHW_PERSIST_TRACE") && atoi(getenv("DHW_PERSIST_TRACE"))) {
+    if (!h->d_step_trace && dev_alloc(h, (void**)&h->d_step_trace, (size_t)h->persist_grid * STEP_MAX_PHASES * 4 * 8)) return nullptr;
+    host.back().trace = h->d_step_trace;
+  }
+  if (dev_alloc(h, (void**)&sp.dev, host.size() * sizeof(StepPlan), false)) return nullptr;
+  if (hipMemcpy(sp.dev, host.data(), host.size() * sizeof(StepPlan), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  sp.ok = true;
+  return sp.dev;
+}
+
 // All sub-batches of one dhw_sample call.  On a capturing stream the sub-batches fork onto the handle's
 // side streams (parallel graph branches) and join back; eagerly (profiling) they run one after another.
 static int sample_enqueue_all(dhw_handle* h, bool fork, int B, const int64_t* text, const float* style, int L, int Lt,
                               int T, int mode, const float* noise, float* out, hipStream_t st,
-                              const std::vector<float>& beta, const std::vector<float>& alpha) {
+                              const std::vector<float>& beta, const std::vector<float>& alpha, const StepPlan* d_plans = nullptr) {
   const int ns = std::min(h->nstreams, B);
   const int per = (B + ns - 1) / ns;
   h->taps.clear();
   if (!fork || ns == 1) {
     for (int s = 0, b0 = 0; b0 < B; ++s, b0 += per) {
-      int rc = sample_enqueue(h, &h->ws[s], b0, std::min(per, B - b0), B, text, style, L, Lt, T, mode, noise, out, st, beta, alpha);
+      int rc = sample_enqueue(h, &h->ws[s], b0, std::min(per, B - b0), B, text, style, L, Lt, T, mode, noise, out, st, beta, alpha, ns == 1 ? d_plans : nullptr);
       if (rc) return rc;
     }
     return 0;
@@ -1473,6 +1612,18 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
   if ((rc = dhw_finalize(h))) return rc;
   HIPCK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)hip_stream;
+  if (h->h_step_err && *(volatile unsigned*)h->h_step_err) {
+    // a persistent step kernel gave up waiting (bounded spin, persist.h): its results were wrong; say so and fall back for good
+    const unsigned code = *(volatile unsigned*)h->h_step_err;
+    *(volatile unsigned*)h->h_step_err = 0;
+    h->persist = false;
+    hipDeviceSynchronize();
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    if (h->d_step_sync) hipMemset(h->d_step_sync, 0, h->step_sync_words * sizeof(unsigned));
+    return fail(h, DHW_ERR_HIP, "persistent step kernel timed out waiting for phase %u in an EARLIER call (its samples were invalid); "
+                "persistent launches are now disabled for this handle", code - 1);
+  }
   dhw_handle::FilmT* ft = nullptr;
   if ((rc = ensure_film_T(h, T, &ft))) return rc;
   h->d_film_T = ft->d_film;
@@ -1511,6 +1662,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
       HIPCK(h, hipDeviceSynchronize());
       for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // they captured the old staging pointer
       h->graphs.clear();
+      h->plans.clear();   // (so did the step plans)
       if ((rc = dev_alloc(h, (void**)&h->d_noise_stage, need * 4, false))) return rc;
       h->noise_stage_cap = need;
     }
@@ -1524,14 +1676,15 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
     // profiling keeps one stream so the per-launch events bracket one kernel each
     rc = sample_enqueue_all(h, !h->prof, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain};
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain, (uint64_t)h->persist};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
+      const StepPlan* d_plans = ensure_step_plans(h, key, B, L, Lt, T, mode, nz, beta, alpha);   // (before the capture: it uploads)
       hipStream_t cs;
       HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
       if (e != hipSuccess) { hipStreamDestroy(cs); return fail(h, DHW_ERR_HIP, "begin capture: %s", hipGetErrorString(e)); }
-      rc = sample_enqueue_all(h, true, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha);
+      rc = sample_enqueue_all(h, true, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha, d_plans);
       hipGraph_t g = nullptr;
       e = hipStreamEndCapture(cs, &g);
       if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
@@ -1665,6 +1818,23 @@ int dhw_set_streams(dhw_handle* h, int n) {
   if (!h || n < 1) return DHW_ERR_ARG;
   h->nstreams = std::min(n, h->nstreams_alloc);
   return h->nstreams;
+}
+// shapes of dhw_sample that run as one persistent launch per denoiser call (persist.h): cached plans that are in use
+int dhw_debug_persist_plans(dhw_handle* h) {
+  if (!h) return DHW_ERR_ARG;
+  int n = 0;
+  for (auto& kv : h->plans) n += kv.second.ok ? 1 : 0;
+  return n;
+}
+// diagnostics: the stamps of the last persistent step (see persist.hip, PTRACE) -> host_dst[workgroups * STEP_MAX_PHASES * 4]; returns
+// the number of workgroups (0 = no trace buffer: DHW_PERSIST_TRACE was not set when the plans were built)
+int dhw_debug_persist_trace(dhw_handle* h, unsigned long long* host_dst, int64_t max_words) {
+  if (!h || !host_dst) return DHW_ERR_ARG;
+  if (!h->d_step_trace) return 0;
+  const int64_t n = (int64_t)h->persist_grid * STEP_MAX_PHASES * 4;
+  if (max_words < n) return DHW_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_dst, h->d_step_trace, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return DHW_ERR_HIP;
+  return h->persist_grid;
 }
 int dhw_set_graph(dhw_handle* h, int on) {
   if (!h) return DHW_ERR_ARG;

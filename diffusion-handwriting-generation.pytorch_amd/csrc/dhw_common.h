@@ -19,6 +19,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DHW_DEV __device__ __forceinline__
 
+// The thread index a fused block body works with.  In the persistent per-step kernel (persist.hip, -> DHW_OPAQUE_TID) the
+// bodies run inside a loop over phases: everything they derive from the thread index (tile addresses, lane offsets of the
+// weight stream, ...) is loop-invariant there, and hipcc hoisted all of it in front of the loop — hundreds of values live
+// across every body, 836 spilled VGPRs.  An opaque copy per body invocation keeps those computations where they are used.
+#ifdef DHW_OPAQUE_TID
+__device__ __forceinline__ int body_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#else
+__device__ __forceinline__ int body_tid() { return threadIdx.x; }
+#endif
+
 // Diagnostic per-stage time stamps (s_memrealtime -> p.stamps[slot]) exist only in builds with -DDHW_STAMPS (the
 // micro-benchmarks under tools/).  Even behind a run-time `if (p.stamps ...)` the stamp blocks changed the product's code:
 // each is a conditional region with a global store, and hipcc's s_waitcnt bookkeeping at the region's join point waited

@@ -141,8 +141,9 @@ constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) 
 // p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
 // ConvBlock or the previous layer's enc_bc continues into the next layer without a launch boundary.  VPIECE = bytes per
 // store of the transposed v2 tile (16, or 4 when m0 is only even).
-template <typename T, int DM, int BM, int VPIECE = 16>
-DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0, int rows_valid) {
+// P: EncLayerParams — a kernel argument, or the same struct in the constant address space (persist.hip: parameters in a plan in memory).
+template <typename T, int DM, int BM, int VPIECE = 16, typename P>
+DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_valid) {
   constexpr int ES = sizeof(T);
   // GEMM stages: every wave covers all BM rows and 1/WN of the channels, so no two waves stream the same weight
   // fragments (row groups would re-fetch them: the L2 -> CU weight stream is what bounds these kernels).  DM = 192 has
@@ -150,7 +151,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   static_assert(NT * WN * 16 == DM, "channel tiles must divide over the waves");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const bool act = WN == 8 || wave < WN;
   const int wm = 0, wn = act ? wave : 0;
@@ -208,7 +209,7 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
   }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
   PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
-  pad.load(trow, 0, p.Lt);
+  pad.load(lane, trow, 0, p.Lt);
   // the q1 weights are requested BEHIND the staging loads: a wave's loads complete in order and the L1 miss queue is
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
@@ -259,13 +260,13 @@ DHW_DEV void enc_a_body(const EncLayerParams& p, const EncALds& m, int b, int m0
       for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
     }
     for (int kb = 0; kb < p.Lt; kb += KBC) {
-      if (kb) pad.load(trow, kb, p.Lt);
+      if (kb) pad.load(lane, trow, kb, p.Lt);
       const unsigned padbits = pad.bits();
       if (kb) {
         attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
       }
-      attn_units<T, KBC, true, UMAX>(qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
+      attn_units<T, KBC, true, UMAX>(lane, qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
       if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
                                              // barrier behind the a1 store below does)
     }

@@ -1,0 +1,385 @@
+// enc_bc_core.h — the second half of an EncoderLayer's stroke side (reference model.py:49-58) for one row tile of one
+// sample as a device function, the stand-alone layout of the first half, and their LDS budgets (see enclayer.hip).
+#pragma once
+#include "enc_a_core.h"
+
+namespace {
+
+
+
+#define STAMP(slot) ENC_STAMP(slot)
+// per-wave stamps of enc_bc (diagnostic builds, tools/bench_encw.cpp): shader-clock time of every wave of workgroup 0 at the
+// phase boundaries inside the stages -> p.stamps[64 + wave * 32 + slot]
+#ifdef DHW_STAMPS
+#define WST(slot) do { if (p.stamps && blockIdx.x == 0 && lane == 0) p.stamps[64 + wave * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WST(slot) do { } while (0)
+#endif
+
+// enc_a for the BM-row tile at m0 of sample b with the stand-alone LDS layout (x tile | q1 tile | LayerNorm scratch | text K/V | parameters)
+template <typename T, int DM, int BM, typename P>
+DHW_DEV void enc_a_tile(const P& p, const int b, const int m0, char* smem) {
+  const int S = tile_stride<T>(DM);
+  EncALds m;
+  m.XR = smem;
+  m.QR = m.XR + BM * S;
+  m.red = reinterpret_cast<float*>(m.QR + BM * S);
+  m.KT = reinterpret_cast<char*>(m.red) + 2 * 8 * BM * sizeof(float);
+  m.VT = m.KT + 32 * tile_stride<T>(DM);
+  m.VS = smem;   // spans the x2 and q1 tiles: DM * (BM * ES + 16) <= 2 * BM * S
+  m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DM, BM>());
+  enc_a_body<T, DM, BM>(p, m, b, m0, min(BM, p.Lk - m0));
+}
+
+// Self-attention K / V staging.  bf16: 64-key blocks, DOUBLE buffered when two blocks of K [keys][DM] + V^T [DM][keys] fit
+// beside the a2 tile (they overlay the x3 / FFN tiles, which are written only after the attention): the next block's
+// global loads are in flight during the current block's softmax / MFMA work and only their LDS stores remain afterwards.
+// (Single-buffered 128-key blocks spent as long in the two dependent copy round trips per block as in the math:
+// profiles/r03_head_enclayer_stage_stamps.log, d = 192: staged 2.7 / 2.0 us, computed 3.3 / 3.3 us.)
+// fp32 parity mode: single-buffered 32-key blocks (its tiles are twice as wide).
+template <typename T, int DM, int BM>
+constexpr size_t self_att_bytes(int kbs, int nbuf, int vpad = 16) { return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + vpad)); }
+template <typename T, int DM, int BM>
+constexpr int self_kbs() { return sizeof(T) == 2 ? 64 : 32; }
+template <typename T, int DM, int BM>
+constexpr bool self_db() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, 2) <= 160 * 1024; }
+// V^T row pad: the conflict-free 32 bytes when the staging buffers still fit, else 16 (attn_core.h)
+template <typename T, int DM, int BM>
+constexpr int self_vpad() { return sizeof(T) == 2 && self_att_bytes<T, DM, BM>(64, self_db<T, DM, BM>() ? 2 : 1, 32) <= 160 * 1024 ? 32 : 16; }
+template <typename T, int DM, int BM>
+constexpr size_t lds_bc_tiles() {
+  constexpr size_t S = tile_stride<T>(DM);
+  constexpr size_t stages = 3 * BM * S + 2 * 8 * BM * sizeof(float), att = self_att_bytes<T, DM, BM>(self_kbs<T, DM, BM>(), self_db<T, DM, BM>() ? 2 : 1, self_vpad<T, DM, BM>());
+  return stages > att ? stages : att;
+}
+// enc_bc's parameter block (bf16 kernels): [b_d2 | gamma2 | beta2 | b_f1 (2 vectors) | b_f2 | gamma3 | beta3].  It sits behind
+// the tiles when that fits the 160 KiB; the double-buffered d = 256 variants have 3 KB to spare, there the block is written
+// after the last key block into the staging buffer that block does NOT use (free since the previous iteration's barrier).
+template <typename T, int DM> constexpr size_t enc_bc_param_bytes() { return enc_plds<T>() ? (size_t)8 * DM * sizeof(float) : 0; }
+template <typename T, int DM, int BM>
+constexpr bool bc_params_fixed() { return lds_bc_tiles<T, DM, BM>() + enc_bc_param_bytes<T, DM>() <= 160 * 1024; }
+template <typename T, int DM, int BM>
+constexpr size_t lds_bc_bytes() { return lds_bc_tiles<T, DM, BM>() + (bc_params_fixed<T, DM, BM>() ? enc_bc_param_bytes<T, DM>() : 0); }
+
+// NEXT: 0, or the EncChain mode compiled into this variant (DN = width of the chained layer)
+template <typename T, int DM, int BM, int NEXT>
+constexpr size_t lds_bc_chain_bytes() {
+  constexpr size_t S = tile_stride<T>(DM), base = 3 * BM * S + 2 * 8 * BM * sizeof(float);
+  constexpr size_t chain = NEXT == 1 ? base + enc_a_text_kv_bytes<T, DM, BM>() + enc_a_param_bytes<T, DM>()
+                         : NEXT == 2 ? base + enc_a_text_kv_bytes<T, 384, BM / 2>() + enc_a_param_bytes<T, 384>() : 0;
+  return chain > lds_bc_bytes<T, DM, BM>() ? chain : lds_bc_bytes<T, DM, BM>();
+}
+
+template <typename T, int DM, int BM>
+constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, DM, BM>() + enc_a_param_bytes<T, DM>(); }
+
+// The second half of the layer for the BM-row tile at m0 of sample b (+ what NEXT chains behind it), as a device function over
+// the workgroup's LDS: the per-launch kernel (enclayer.hip) and the persistent per-step kernel (persist.hip) both run it.
+template <typename T, int DM, int BM, int NEXT = 0, typename P, typename X>
+DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, char* smem) {
+  constexpr int ES = sizeof(T);
+  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
+  constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
+  constexpr int RING = sizeof(T) == 4 ? 12 : (DM == 384 ? 15 : 24);   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
+  const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
+  const int wm = 0, wn = act ? wave : 0;
+  const int S = tile_stride<T>(DM);
+  char* R1 = smem;               // a2, later SiLU(x3)
+  char* R2 = R1 + BM * S;        // x3
+  char* R3 = R2 + BM * S;        // one DM-wide half of the FFN hidden layer
+  float* red = reinterpret_cast<float*>(R3 + BM * S);
+  const float* gam = p.film + (size_t)b * p.film_bs;
+  const float* bet = gam + p.film_tot;
+  const int row0 = wm * (BM / WM), ntile0 = wn * NT;
+  const int n0 = ntile0 * 16 + 4 * g;
+  const size_t wlane = ((size_t)ntile0 * KC * 64 + lane) * 8;
+  const char* op1 = R1 + (row0 + l15) * S + g * 8 * ES;
+  const char* op3 = R3 + (row0 + l15) * S + g * 8 * ES;
+
+  WRing<T, NT, RING> ring;
+  EpiParams<NT> ep;
+  constexpr bool PLDS = enc_plds<T>(), PLFIX = bc_params_fixed<T, DM, BM>();
+  float* PL = reinterpret_cast<float*>(smem + lds_bc_tiles<T, DM, BM>());   // (PLFIX; else chosen behind the attention loop)
+  ParamStage<8> cp;
+  // (a macro, not a lambda: with `cp` captured by a closure hipcc kept it in scratch memory)
+#define BC_PARAMS_REQUEST() cp.template load<DM>(tid, p.b_d2, gam + p.f2, bet + p.f2, p.b_f1, p.b_f1 + DM, p.b_f2, gam + p.f3, bet + p.f3)
+  STAMP(16);
+  WST(0);
+  DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 40, __builtin_amdgcn_s_memtime());
+  if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
+    constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
+    constexpr bool DB = self_db<T, DM, BM>();
+    constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + self_vpad<T, DM, BM>();
+    constexpr int BUFB = KBS * SK + DM * SV;   // one staged block: K tile, then V^T tile
+    const int rg = wave % RG, hs = wave / RG;
+    const T* qk = reinterpret_cast<const T*>(p.qk2);
+    const T* ksrc = qk + (size_t)b * p.Lk * 2 * DM + DM;
+    const T* vsrc = reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX;
+    constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBS / EPV;
+    constexpr int UK = (KBS * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
+    CopyRegs<UK> ck;
+    CopyRegs<UV> cv;
+    // K rows [kb, kb + KBS) x DM channels and V^T rows [0, DM) x keys [kb, kb + KBS): requested at clamped (valid) addresses;
+    // K rows at or past Lk and V^T pieces past lpadX are zero-filled by the store
+    auto request = [&](int kb) {
+      ck.load(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                                 return reinterpret_cast<const uint4*>(ksrc + (size_t)min(kb + r, p.Lk - 1) * 2 * DM + cc * EPV); });
+      cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                                                return reinterpret_cast<const uint4*>(vsrc + (size_t)ch * p.lpadX + (kb + (part + 1) * EPV <= p.lpadX ? kb + part * EPV : 0)); });
+    };
+    auto commit = [&](int kb, char* KT, char* VT) {
+      ck.store(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SK + cc * 16); },
+               [&](int id) { return kb + id / CPR < p.Lk; });
+      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SV, part, v); },
+                  [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
+    };
+    Frag<T> qf[UMAX][2];
+    float mr[UMAX], lr[UMAX];
+    f32x4 o[UMAX][4];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + (h < H ? h : 0) * 64 + 8 * g;
+      qf[u][0] = frag_load(qrow);
+      qf[u][1] = frag_load(qrow + 32);
+      mr[u] = -INFINITY;
+      lr[u] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0, 0, 0, 0};
+    }
+    if constexpr (PLDS) BC_PARAMS_REQUEST();   // (!PLFIX: held in registers across the key blocks, 8 VGPRs)
+    request(0);   // (one round trip together with the q fragments)
+    if constexpr (PLDS && PLFIX) cp.template store<DM>(PL, tid);
+    commit(0, R2, R2 + KBS * SK);
+    lds_barrier();
+    int ib = 0;
+    for (int kb = 0; kb < p.Lk; kb += KBS, ++ib) {
+      const bool more = kb + KBS < p.Lk;
+      char* KT = R2 + (DB && (ib & 1) ? BUFB : 0);
+      char* VT = KT + KBS * SK;
+      char* KN = R2 + (DB && !(ib & 1) ? BUFB : 0);   // where the next block goes
+      if (DB && more) request(kb + KBS);
+      if (ib < 3) STAMP(26 + 2 * ib);
+      attn_units<T, KBS, false, UMAX>(lane, qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
+      if (ib < 3) STAMP(27 + 2 * ib);
+      if (more) {
+        if (!DB) {          // single buffer: every wave must be past its reads before the tiles are rewritten
+          lds_barrier();
+          request(kb + KBS);
+        }
+        commit(kb + KBS, KN, KN + KBS * SK);
+        lds_barrier();      // next block complete (double buffer: its previous contents were read one iteration ago)
+      }
+      // (after the last block the barrier behind the a2 store below separates the staging tiles from their next use)
+    }
+    if constexpr (PLDS && !PLFIX) {
+      // the last block (index ib - 1) was read from buffer (ib - 1) & 1; the other one is free: its readers finished an
+      // iteration ago, behind a barrier.  In buffer 0 the block goes behind the stage tiles and the LayerNorm scratch.
+      static_assert(DB, "a single staging buffer leaves room for a fixed parameter block");
+      static_assert((size_t)2 * BM * tile_stride<T>(DM) + 2 * 8 * BM * sizeof(float) + enc_bc_param_bytes<T, DM>() <= (size_t)BUFB, "parameter block inside buffer 0");
+      PL = reinterpret_cast<float*>(((ib - 1) & 1) ? R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float) : R2 + BUFB);
+      cp.template store<DM>(PL, tid);
+    }
+    WST(1);
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int h = hs + u * HS;
+      float l = lr[u];
+      l = xg_sum(l);
+      const float inv = 1.0f / l;
+      if (h < H) {
+        T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
+      }
+    }
+  }
+  else if constexpr (PLDS) {   // (diagnostic path without the attention stage)
+    BC_PARAMS_REQUEST();
+    if constexpr (!PLFIX) PL = reinterpret_cast<float*>(R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float));
+    cp.template store<DM>(PL, tid);
+  }
+  if (act) {
+    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
+    if constexpr (!PLDS) ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
+  }
+  WST(2);
+  lds_barrier();
+  WST(3);
+  STAMP(17);
+
+  {  // ---- x3 = FiLM2(LN(x2 + Wd a2 + b))
+    f32x4 acc[NT][MT];
+    acc_zero(acc);
+    if (act) {
+      f32x4 res[NT][MT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          // unconditional (rows past the sample read the next sample / the buffer's slack rows and are never written
+          // back): a per-lane `r < Lk ? load : 0` compiles to a branch with s_waitcnt vmcnt(0) inside, which drains the
+          // weight prefetch issued in front of the barrier — once per row tile
+          const int r = m0 + row0 + j * 16 + l15;
+          res[i][j] = load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i));
+        }
+      ring.template run_s<MT, KC>(acc, op1, S, KC);
+      WST(4);
+      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+      WST(5);
+      if constexpr (PLDS) ep.lds(PL, PL + DM, PL + 2 * DM, n0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
+    }
+    STAMP(18);
+    WST(6);
+    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    WST(7);
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const int r = row0 + j * 16 + l15;
+          f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
+          store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
+          store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
+        }
+    }
+  }
+  WST(8);
+  lds_barrier();
+  WST(9);
+  STAMP(19);
+
+  // ---- out = FiLM3(LN(W2 SiLU(W1 SiLU(x3) + b1) + b2 + x3)); the 2*DM hidden layer is processed in two halves
+  f32x4 acc2[NT][MT];
+  acc_zero(acc2);
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    if (act) {
+      f32x4 acc[NT][MT];
+      acc_zero(acc);
+      if constexpr (!PLDS) ep.load_bias(p.b_f1 + hh * DM, n0);
+      ring.template run_s<MT, KC>(acc, op1, S, KC);
+      WST(10 + 6 * hh);
+      if constexpr (PLDS) ep.lds_bias(PL + (3 + hh) * DM, n0);
+      // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
+      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
+      WST(11 + 6 * hh);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          f32x4 v = acc[i][j] + ep.bias[i];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
+          store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v);
+        }
+    }
+    WST(12 + 6 * hh);
+    lds_barrier();
+    WST(13 + 6 * hh);
+    STAMP(20 + 2 * hh);
+    if (act) {
+      ring.template run_s<MT, KC>(acc2, op3, S, KC);
+      WST(14 + 6 * hh);
+      if (hh == 0) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // FFN half 1
+    }
+    if (hh == 0) lds_barrier();   // R3 is rewritten by the next half (after the last one the LayerNorm barrier below does)
+    WST(15 + 6 * hh);
+    STAMP(21 + 2 * hh);
+  }
+  if (act) {
+    if constexpr (PLDS) ep.lds(PL + 5 * DM, PL + 6 * DM, PL + 7 * DM, n0);
+    else ep.load(p.b_f2, gam + p.f3, bet + p.f3, n0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        acc2[i][j] += ep.bias[i] + load4(reinterpret_cast<const T*>(R2 + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
+  }
+  WST(22);
+  ln_rows<T, MT, NT, WN, BM>(acc2, red, wn, row0, lane, DM, act);
+  WST(23);
+  // out tile -> LDS (R3 is free: the last FFN half was consumed two barriers ago) -> coalesced rows
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+        store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc2[i][j] * ep.gam[i] + ep.bet[i]);
+  }
+  lds_barrier();
+  const int rows_valid = min(BM, p.Lk - m0);
+  tile_copy_out<T>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
+  if (p.pool)
+    tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
+  STAMP(24);
+  WST(24);
+  DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, 41, __builtin_amdgcn_s_memtime());
+
+  if constexpr (NEXT == 1) {
+    // the next layer's enc_a on the out tile (R3): q1 / a1 in R1, the v2 staging area over R1..R2 (both dead by now)
+    EncALds m;
+    m.XR = R3; m.QR = R1; m.red = red;
+    m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    m.VT = m.KT + 32 * tile_stride<T>(DM);
+    m.VS = R1;
+    m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DM, BM>());
+    enc_a_body<T, DM, BM>(nx.a, m, b, m0, rows_valid);
+  } else if constexpr (NEXT == 2) {
+    // AvgPool1d(2) of the out tile -> R1; Linear DM -> DN (att_dense) -> x tile of the first attention layer; its enc_a
+    constexpr int DN = 384, BN2 = BM / 2, SN = tile_stride<T>(DN), NTN = DN / 8 / 16, MTN = BN2 / 16;
+    {
+      constexpr int EPV = 16 / ES;
+      const int cpr = DM / EPV;
+      for (int id = tid; id < BN2 * cpr; id += 512) {
+        const int r = id / cpr, cc = id - r * cpr;
+        uint4 a = *reinterpret_cast<const uint4*>(R3 + (2 * r) * S + cc * 16);
+        const uint4 bq = *reinterpret_cast<const uint4*>(R3 + (2 * r + 1) * S + cc * 16);
+        T* ea = reinterpret_cast<T*>(&a);
+        const T* eb = reinterpret_cast<const T*>(&bq);
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) ea[k] = from_f<T>(0.5f * (to_f(ea[k]) + to_f(eb[k])));
+        *reinterpret_cast<uint4*>(R1 + r * S + cc * 16) = a;
+      }
+    }
+    WRing<T, NTN> rd;
+    EpiParams<NTN> epd;
+    const int nt0 = wave * NTN, nn0 = nt0 * 16 + 4 * g;
+    rd.template fill_s<KC>(reinterpret_cast<const T*>(nx.w_dense) + ((size_t)nt0 * KC * 64 + lane) * 8);
+    epd.load_bias(nx.b_dense, nn0);
+    lds_barrier();   // pooled tile complete; every read of the out tile (copy-out, pooling) is done
+    char* XN = R2;   // x tile of the chained layer, then its q1 tile: together BM * SN <= 2 * BM * S bytes over R2..R3
+    {
+      f32x4 acc[NTN][MTN];
+      acc_zero(acc);
+      rd.template run_s<MTN, KC>(acc, R1 + l15 * S + g * 8 * ES, S, KC);
+#pragma unroll
+      for (int i = 0; i < NTN; ++i)
+#pragma unroll
+        for (int j = 0; j < MTN; ++j)
+          store4(reinterpret_cast<T*>(XN + (j * 16 + l15) * SN) + nn0 + 16 * i, acc[i][j] + epd.bias[i]);
+    }
+    lds_barrier();
+    const int m02 = m0 / 2, rows2 = rows_valid / 2;
+    tile_copy_out<T>(XN, SN, reinterpret_cast<T*>(nx.dense_out) + (size_t)(b * (p.Lk / 2) + m02) * DN, DN, rows2, DN, tid, 512);
+    EncALds m;
+    m.XR = XN; m.QR = XN + BN2 * SN; m.red = red;
+    m.KT = reinterpret_cast<char*>(red) + 2 * 8 * BM * sizeof(float);
+    m.VT = m.KT + 32 * tile_stride<T>(DN);
+    m.VS = XN;
+    m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, DN, BN2>());
+    enc_a_body<T, DN, BN2>(nx.a, m, b, m02, rows2);
+  }
+}
+
+
+}  // namespace

@@ -81,18 +81,19 @@ DHW_DEV uint2 pack4_bf16(const f32x4& v) {
 // zeros; do0 / do1: false = the row of that tile is not written at all.  After the swap lane (l15, g) holds channels
 // 8 (g >> 1) .. + 7 of row l15 of tile (g & 1), i.e. the 16 bytes at (g & 1 ? p1 - 8 bytes : p0).
 // Must be called by all 64 lanes (v_permlane16_swap reads the partner lanes' registers).
-DHW_DEV void store_pair(bf16_t* p0, bf16_t* p1, const f32x4& v0, const f32x4& v1, bool keep0 = true, bool keep1 = true,
+// lane: the caller's lane index (a body derives it from body_tid(), dhw_common.h: never from threadIdx.x directly)
+DHW_DEV void store_pair(int lane, bf16_t* p0, bf16_t* p1, const f32x4& v0, const f32x4& v1, bool keep0 = true, bool keep1 = true,
                         bool do0 = true, bool do1 = true) {
   uint2 a = pack4_bf16(v0), b = pack4_bf16(v1);
   a.x = keep0 ? a.x : 0u; a.y = keep0 ? a.y : 0u;
   b.x = keep1 ? b.x : 0u; b.y = keep1 ? b.y : 0u;
   const auto lo = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
   const auto hi = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
-  const bool odd = (threadIdx.x >> 4) & 1;
+  const bool odd = (lane >> 4) & 1;
   char* dst = odd ? reinterpret_cast<char*>(p1) - 8 : reinterpret_cast<char*>(p0);
   if (odd ? do1 : do0) *reinterpret_cast<uint4*>(dst) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
 }
-DHW_DEV void store_pair(float* p0, float* p1, const f32x4& v0, const f32x4& v1, bool keep0 = true, bool keep1 = true,
+DHW_DEV void store_pair(int lane, float* p0, float* p1, const f32x4& v0, const f32x4& v1, bool keep0 = true, bool keep1 = true,
                         bool do0 = true, bool do1 = true) {
   if (do0) store4(p0, keep0 ? v0 : (f32x4){0, 0, 0, 0});
   if (do1) store4(p1, keep1 ? v1 : (f32x4){0, 0, 0, 0});
@@ -106,20 +107,20 @@ DHW_DEV void store_one(T* p, const f32x4& v, bool keep = true, bool doit = true)
 // n0 + 16 i + 0..3 (n0 includes this lane's 4 (lane >> 4)).  keep(j): the lane's row of row tile j is real (else zeros);
 // valid(j): it is written at all.  Tiles are paired in (i, j) order; an odd tile count leaves one 8-byte store.
 template <typename T, int NT, int MT, typename KeepF, typename ValidF>
-DHW_DEV void store_tiles(char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT], KeepF keep, ValidF valid) {
-  const int l15 = threadIdx.x & 15;
+DHW_DEV void store_tiles(int lane, char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT], KeepF keep, ValidF valid) {
+  const int l15 = lane & 15;
   constexpr int N = NT * MT;
   auto ptr = [&](int t) { const int i = t / MT, j = t - i * MT; return reinterpret_cast<T*>(tile + (row0 + j * 16 + l15) * S) + n0 + 16 * i; };
 #pragma unroll
   for (int t = 0; t + 1 < N; t += 2) {
     const int j0 = t % MT, j1 = (t + 1) % MT;
-    store_pair(ptr(t), ptr(t + 1), v[t / MT][j0], v[(t + 1) / MT][j1], keep(j0), keep(j1), valid(j0), valid(j1));
+    store_pair(lane, ptr(t), ptr(t + 1), v[t / MT][j0], v[(t + 1) / MT][j1], keep(j0), keep(j1), valid(j0), valid(j1));
   }
   if constexpr (N & 1) store_one<T>(ptr(N - 1), v[NT - 1][MT - 1], keep(MT - 1), valid(MT - 1));
 }
 template <typename T, int NT, int MT>
-DHW_DEV void store_tiles(char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT]) {
-  store_tiles<T, NT, MT>(tile, S, row0, n0, v, [](int) { return true; }, [](int) { return true; });
+DHW_DEV void store_tiles(int lane, char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT]) {
+  store_tiles<T, NT, MT>(lane, tile, S, row0, n0, v, [](int) { return true; }, [](int) { return true; });
 }
 
 // 8 packed bf16 (one 16-byte piece of a staged tile) -> SiLU of each, packed again; fp32: 4 values
@@ -146,8 +147,8 @@ DHW_DEV uint4 silu_piece(const uint4& w) {
 // those requests are spread between the pairs' VALU work instead of blocking in front of it.  The scheduling barrier keeps
 // hipcc from clustering the loads again.  Returns the number of pairs processed (= calls of between()).
 template <typename T, int NT, int MT, bool SILU, typename AffF, typename KeepF, typename ValidF, typename BetweenF>
-DHW_DEV void epilogue_pairs(char* tile, int S, int row0, int n0, const f32x4 (&acc)[NT][MT], AffF aff, KeepF keep, ValidF valid, BetweenF between) {
-  const int l15 = threadIdx.x & 15;
+DHW_DEV void epilogue_pairs(int lane, char* tile, int S, int row0, int n0, const f32x4 (&acc)[NT][MT], AffF aff, KeepF keep, ValidF valid, BetweenF between) {
+  const int l15 = lane & 15;
   constexpr int N = NT * MT;
   auto ptr = [&](int t) { const int i = t / MT, j = t - i * MT; return reinterpret_cast<T*>(tile + (row0 + j * 16 + l15) * S) + n0 + 16 * i; };
 #pragma unroll
@@ -155,7 +156,7 @@ DHW_DEV void epilogue_pairs(char* tile, int S, int row0, int n0, const f32x4 (&a
     const int i0 = t / MT, j0 = t % MT, i1 = (t + 1) / MT, j1 = (t + 1) % MT;
     f32x4 v[2] = {aff(i0, acc[i0][j0]), aff(i1, acc[i1][j1])};
     if constexpr (SILU) silu_tiles<T, 2>(v);
-    store_pair(ptr(t), ptr(t + 1), v[0], v[1], keep(j0), keep(j1), valid(j0), valid(j1));
+    store_pair(lane, ptr(t), ptr(t + 1), v[0], v[1], keep(j0), keep(j1), valid(j0), valid(j1));
     between(t / 2);
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -33,7 +33,9 @@ DHW_DEV void normal2(uint64_t seed, int64_t sample, int pos, int iter, float& z0
 }
 
 // a0, a1: eps dot products (without bias); a2: pen-lift logit (without bias); row: global stroke row
-DHW_DEV void heads_finish(const HeadsParams& p, long row, float a0, float a1, float a2) {
+// (HP: HeadsParams, or the same struct in the constant address space when the caller's parameters live in a plan in memory)
+template <typename HP>
+DHW_DEV void heads_finish(const HP& p, long row, float a0, float a1, float a2) {
   const float e0 = a0 + p.b_out[0], e1 = a1 + p.b_out[1];
   const float pen = 1.0f / (1.0f + expf(-(a2 + p.b_pen[0])));
   if (p.eps) { p.eps[row * 2] = e0; p.eps[row * 2 + 1] = e1; }

@@ -207,6 +207,10 @@ class DiffusionModel(nn.Module):
             _lib.check(_lib.lib().dhw_debug_set_teacher(self._handle, reset.data_ptr() if every else None, cap.data_ptr() if every else None, every),
                        self._handle)
 
+    def persistent_plans(self) -> int:
+        """Number of `sample` shapes that ran every denoiser call as ONE persistent launch (csrc/persist.h; 0 = kernel by kernel)."""
+        return int(_lib.lib().dhw_debug_persist_plans(self._handle)) if self._handle else 0
+
     def profile(self, on: bool):
         _lib.check(_lib.lib().dhw_profile_enable(self._handle, int(on)), self._handle)
         if on:

@@ -294,14 +294,18 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     inp = spec.synthetic_inputs(B, L, Lt, seed=12, pad=1, T=T)
     tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
     outs = {}
-    for name, env in (("default", {}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
+    for name, env in (("default", {}), ("persist", {"DHW_PERSIST": "1"}), ("no_plane", {"DHW_PLANE": "0"}), ("no_fused_heads", {"DHW_FUSE_HEADS": "0"}),
                       ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("no_chain", {"DHW_CHAIN": "0"}), ("conv_chain", {"DHW_CHAIN_CONV": "3"}),
                       ("no_conv_chain", {"DHW_CHAIN_CONV": "0"}),
                       ("enc_bm64", {"DHW_ENC_BM": "64"}), ("enc_bm32", {"DHW_ENC_BM": "32"}), ("conv_bm64", {"DHW_CONV_BM": "64"}),
                       ("f32_enc_per_gemm", {"DHW_FUSE_F32": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
         outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
+        # DHW_PERSIST=1 (bf16): every denoiser call is ONE persistent launch (csrc/persist.h); every other configuration launches kernel by kernel
+        assert m.persistent_plans() == (1 if (prec == "bf16" and name == "persist") else 0), name
     assert torch.equal(outs["default"], outs["no_plane"])
+    # the persistent launch runs the same block bodies (with its own canonical row tiles) behind per-sample counters: same bits
+    assert torch.equal(outs["default"], outs["persist"]), "persistent launch"
     # fused vs unfused block kernels round intermediates to bf16 at different points; |x| reaches ~9 after these 7 steps.
     # Measured (r2): <= 0.03 for every pair
     tol = 1e-4 if prec == "fp32" else 0.06

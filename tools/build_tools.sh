@@ -29,10 +29,3 @@ if [ -n "$DHW_BUILD_ABL" ]; then
       hipcc --offload-arch=gfx950 tools/bin/bench_conv.o /tmp/convblock_abl$abl.o $P/enclayer.o -o tools/bin/bench_conv_abl$abl
   done
 fi
-# ablation build of the EncoderLayer bench (diagnostics; ENC16_ABL bit mask, see csrc/enc16_core.h): tools/bin/bench_enc_abl<N>
-if [ -n "$ENC16_BUILD_ABL" ]; then
-  for abl in $ENC16_BUILD_ABL; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDHW_STAMPS -DENC16_ABL=$abl -x hip -c "diffusion-handwriting-generation.pytorch_amd/csrc/enclayer.hip" -o /tmp/enclayer_abl$abl.o &&
-      hipcc --offload-arch=gfx950 tools/bin/bench_enc.o /tmp/enclayer_abl$abl.o -o tools/bin/bench_enc_abl$abl
-  done
-fi
