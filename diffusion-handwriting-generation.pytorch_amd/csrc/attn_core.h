@@ -194,21 +194,27 @@ DHW_DEV void attn_block_lds(int lane, const Frag<T> (&qf)[(D + 31) / 32], const 
 //   * the units' phases are written unit-interleaved (all QK^T MFMAs, all maxima, all exponentials, all PV MFMAs): a wave
 //     that owns two heads overlaps one unit's MFMAs with the other's VALU work instead of running two serial chains.
 // The fp32 parity mode keeps attn_block_lds (exact reference operation order).
-// ---- V^T tiles in LDS (bf16 kernels): [channel][keys], keys PERMUTED inside every 32-key group so that the 8 k-values of a
-// PV operand fragment (keys 4g..4g+3 of the group's first 16-key tile and of its second, the order the P^T accumulators
-// supply) are 16 contiguous bytes: key 16 h + 4 g + r sits at position 8 g + 4 h + r.  One ds_read_b128 per fragment instead
-// of two ds_read_b64 — the LDS operand reads are what bounds the attention stages (profiles/r03_attention_ablation.log) and
-// 8-byte reads reach a fraction of the LDS rate at two waves per SIMD.  Global V^T buffers keep the plain key order; the
-// staging copy scatters each 16-byte piece (8 consecutive keys = two quads of one half h) as two 8-byte stores.
-// Row pad: 32 bytes = conflict-free ds_read_b128 lane groups (gemm_core.h); 16 where LDS is short (one 2-way group).
+// ---- V tiles in LDS.  bf16 kernels: [keys][channels] exactly like the K tile (the projection writes V rows beside the K rows,
+// the staging copy is the same 16-byte-per-lane row copy) and the PV operand — V^T, 16 channels x 32 keys in the k-slot order
+// the P^T accumulators supply (keys 4g .. 4g+3 of the group's first 16-key tile, then of its second) — is read with gfx950's
+// transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block whose row q
+// is addressed by lanes 4q .. 4q+3 (cdna_hip_programming.md, T10).  Two such reads (8 bytes each) per fragment; with the K
+// tile's row padding (stride = 32 mod 128 bytes) the 8 rows a 32-lane half touches tile the 64 banks: conflict-free.
+// This replaced a V^T buffer in memory (written through a 2-byte LDS scatter in the projection epilogue, re-staged key-permuted
+// with 8-byte stores): LDS bank-conflict fraction 0.31 / 0.32 of enc_a / enc_bc, 4-6 MB more write traffic per launch (r3).
+// fp32 parity mode: V^T tiles [channel][keys] as before (the transposing read is a 16-bit instruction).
+typedef __bf16 bf16x4_lds __attribute__((ext_vector_type(4)));
+DHW_DEV Frag<bf16_t> frag_load_tr(const char* p0, const char* p1) {   // rows q = 0..3 at p0 (lane 4q+p: its row, columns 4p..4p+3), rows 4..7 of the fragment at p1
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_lds*)(uintptr_t)p0);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_lds*)(uintptr_t)p1);
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+// (fp32 parity mode) one 16-byte piece of a V^T tile row
 template <typename T> DHW_DEV void vt_store_piece(char* row, int part, const uint4& v) {
-  if constexpr (sizeof(T) == 2) {
-    char* q = row + (part >> 2) * 64 + (part & 1) * 32 + ((part >> 1) & 1) * 8;   // group, g0 = 2 (part & 1), h = (part >> 1) & 1
-    *reinterpret_cast<uint2*>(q) = make_uint2(v.x, v.y);
-    *reinterpret_cast<uint2*>(q + 16) = make_uint2(v.z, v.w);
-  } else {
-    *reinterpret_cast<uint4*>(row + part * 16) = v;   // fp32 parity mode: plain order (attn_block_lds reads two halves)
-  }
+  static_assert(sizeof(T) == 4, "bf16 kernels keep V row-major");
+  *reinterpret_cast<uint4*>(row + part * 16) = v;
 }
 
 #ifndef DHW_ATT_ABL
@@ -271,7 +277,7 @@ DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], 
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int pp = 0; pp < NPF; ++pp)
-        vf[u][t][pp] = (DHW_ATT_ABL & 4) ? qf[u][0] : frag_load(reinterpret_cast<const T*>(vt[u] + (16 * t) * SV + pp * 64 + g * 16));
+        vf[u][t][pp] = (DHW_ATT_ABL & 4) ? qf[u][0] : frag_load_tr(vt[u] + 32 * t + (32 * pp) * SV, vt[u] + 32 * t + (32 * pp + 16) * SV);
   __builtin_amdgcn_sched_barrier(0);
   float m_new[NU], alpha[NU];
 #pragma unroll
@@ -316,32 +322,37 @@ DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], 
       }
 }
 // One KB-key block for the UMAX (1 or 2) units of a wave: unit u = head hs + u * HS, active when that head exists (the
-// second unit of a wave may not).  kt0 / vt0: this lane's LDS row addresses for head 0 (K tile row lane & 15; V^T tile row
-// lane & 15); head h lies h * 64 channels further in both tiles.
+// second unit of a wave may not).  kt / vt: the staged tiles (row stride SK / SV bytes); head h lies h * 64 channels further:
+// columns of the K tile and of the bf16 V tile ([keys][channels]), rows of the fp32 V^T tile ([channels][keys]).
 template <typename T, int KB, bool MASKED, int UMAX>
-DHW_DEV void attn_units(int lane, const Frag<T> (&qf)[UMAX][2], const char* kt0, int SK, const char* vt0, int SV, int hs, int HS, int H, int kb,
+DHW_DEV void attn_units(int lane, const Frag<T> (&qf)[UMAX][2], const char* kt, int SK, const char* vt, int SV, int hs, int HS, int H, int kb,
                         unsigned padbits, int Lk, float (&mr)[UMAX], float (&lr)[UMAX], f32x4 (&o)[UMAX][4]) {
   constexpr int ES = sizeof(T);
+  const int l15 = lane & 15, g = lane >> 4;
+  const char* kt0 = kt + l15 * SK;   // this lane's K row (key l15 of a 16-key tile)
   if constexpr (sizeof(T) == 2) {
+    // this lane's address in a 4-key x 16-channel block of the transposing read: key 4g + (l15 >> 2), channels 4 (l15 & 3) ..
+    const char* vt0 = vt + (4 * g + (l15 >> 2)) * SV + 4 * (l15 & 3) * ES;
     // (both units of a two-head wave in ONE straight-line block — NU = 2 — measured slower: 27.4 vs 26.4 us for the d = 192
     // layer; the LDS operand reads, not the dependent chains, bound this stage: profiles/r03_attention_ablation.log)
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
       if (h < H) {
-        const char* const kt[1] = {kt0 + h * 64 * ES};
-        const char* const vt[1] = {vt0 + h * 64 * SV};
+        const char* const ktu[1] = {kt0 + h * 64 * ES};
+        const char* const vtu[1] = {vt0 + h * 64 * ES};
         float m1[1] = {mr[u]}, l1[1] = {lr[u]};
-        if (kb + KB > Lk) attn_block_bf16<64, KB, MASKED, 1, true>(lane, qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
-        else attn_block_bf16<64, KB, MASKED, 1, false>(lane, qf + u, kt, SK, vt, SV, kb, padbits, Lk, m1, l1, o + u);
+        if (kb + KB > Lk) attn_block_bf16<64, KB, MASKED, 1, true>(lane, qf + u, ktu, SK, vtu, SV, kb, padbits, Lk, m1, l1, o + u);
+        else attn_block_bf16<64, KB, MASKED, 1, false>(lane, qf + u, ktu, SK, vtu, SV, kb, padbits, Lk, m1, l1, o + u);
         mr[u] = m1[0]; lr[u] = l1[0];
       }
     }
   } else {
+    const char* vt0 = vt + l15 * SV;   // V^T row (head channel l15 of a 16-channel tile)
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
-      if (h < H) attn_block_lds<T, 64, KB>(lane, qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV + 4 * (lane >> 4) * ES, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
+      if (h < H) attn_block_lds<T, 64, KB>(lane, qf[u], kt0 + h * 64 * ES, SK, vt0 + h * 64 * SV + 4 * g * ES, SV, kb, padbits, Lk, mr[u], lr[u], o[u]);
     }
   }
 }
@@ -391,7 +402,13 @@ DHW_DEV void attn_stage_kv(char* kt, int SK, char* vt, int SV, const T* ksrc, in
       [&](int id) { const int r = id / cpr, cc = id - r * cpr;
                     return kb + r < kmax ? reinterpret_cast<const uint4*>(ksrc + (size_t)(kb + r) * ldk + cc * EPV) : nullptr; },
       [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(kt + r * SK + cc * 16); });
-  {
+  if constexpr (sizeof(T) == 2) {
+    // V rows [kb, kb + KB) x C channels, row stride `lpad` ELEMENTS here (the caller's V row stride), zero past kmax
+    staged_copy<6>(KB * cpr, tid, nthreads,
+        [&](int id) { const int r = id / cpr, cc = id - r * cpr;
+                      return kb + r < kmax ? reinterpret_cast<const uint4*>(vsrc + (size_t)(kb + r) * lpad + cc * EPV) : nullptr; },
+        [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(vt + r * SV + cc * 16); });
+  } else {
     constexpr int U = 6;
     const int total = C * PPR;
     for (int base = tid; base < total; base += nthreads * U) {

@@ -449,7 +449,8 @@ int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
     const int lp = h->lpadX[i < 2 ? i : 2];
     AA(e.n + ".tl", B * Lt, e.dm); AA(e.n + ".k1", B * Lt, e.dm); AA(e.n + ".vt1", B * e.dm, h->lpadT);
     AA(e.n + ".q1", B * e.rows, e.dm); AA(e.n + ".a1", B * e.rows, e.dm); AA(e.n + ".x2", B * e.rows, e.dm);
-    AA(e.n + ".qk2", B * e.rows, 2 * e.dm); AA(e.n + ".vt2", B * e.dm, lp); AA(e.n + ".a2", B * e.rows, e.dm);
+    // (qk2: the bf16 fused kernels keep [q2 | k2 | v2] rows; the other paths use 2 dm columns of it and the transposed vt2)
+    AA(e.n + ".qk2", B * e.rows, 3 * e.dm); AA(e.n + ".vt2", B * e.dm, lp); AA(e.n + ".a2", B * e.rows, e.dm);
     AA(e.n + ".x3", B * e.rows, e.dm); AA(e.n + ".f", B * e.rows, 2 * e.dm); AA(e.n, B * e.rows, e.dm);
   }
   AA("enc3.pool", B * L / 4, c2); AA("enc5.pool", B * L / 8, c3);
@@ -740,6 +741,9 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
   tap(c, n, n, L, w.cout, out_f32);
 }
 
+// the layer's text values are kept as rows [B*Lt, d] (fused bf16 EncoderLayer kernels) instead of transposed [B][d][lpadT]
+bool v_rows(const dhw_handle* h, const EncLayerW& w) { return h->fuse && h->prec == PREC_BF16 && enclayer_supported(h->prec, w.d, w.heads); }
+
 // model.py:37-58.  The text-side projections (tl, k1, vt1) are produced by enc_layer_text.
 void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
   dhw_handle* h = c.h;
@@ -753,7 +757,18 @@ void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
     p.out = BUF(c, n + ".tl" + c.sfx);
     run_gemm(c, "enc.text_dense", p);
   }
-  {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
+  if (v_rows(h, w)) {
+    // the fused bf16 EncoderLayer kernels read the values as rows [B*Lt, d] (attn_core.h): K and V as two launches of the
+    // stacked [2d x d] weight's halves (this generic text path only runs with DHW_FUSE_TEXT=0 / unsupported text shapes)
+    for (int half = 0; half < 2; ++half) {
+      GemmParams p = gp_base(c, c.Lt, w.d);
+      p.seg[0] = GemmSeg{BUF(c, n + ".tl" + c.sfx), (const char*)w.w_kv1 + (size_t)half * w.d * w.d * h->es, w.d, 1, 0};
+      p.bias0 = w.b_kv1 + half * w.d;
+      if (half == 0) { p.posb = w.pb_k1; p.posb_cols = w.d; }
+      p.out = BUF(c, n + (half ? ".vt1" : ".k1") + c.sfx);
+      run_gemm(c, half ? "enc.v_text" : "enc.k_text", p);
+    }
+  } else {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
     GemmParams p = gp_base(c, c.Lt, 2 * w.d);
     p.seg[0] = GemmSeg{BUF(c, n + ".tl" + c.sfx), w.w_kv1, w.d, 1, 0};
     p.bias0 = w.b_kv1;
@@ -777,7 +792,7 @@ EncLayerParams enc_params(Ctx& c, const std::string& n, const EncLayerW& w, cons
   const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
   if (c.use_plane) {
     k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
-    vt1p += (size_t)c.plane_step * c.B * d * h->lpadT * h->es;
+    vt1p += (size_t)c.plane_step * c.B * (v_rows(h, w) ? c.Lt : h->lpadT) * d * h->es;
   }
   EncLayerParams q{};
   q.B = c.B; q.Lk = Lk; q.Lt = c.Lt; q.d = d; q.heads = w.heads;
@@ -802,7 +817,7 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
   const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
   if (c.use_plane) {
     k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
-    vt1p += (size_t)c.plane_step * c.B * d * h->lpadT * h->es;
+    vt1p += (size_t)c.plane_step * c.B * (v_rows(h, w) ? c.Lt : h->lpadT) * d * h->es;
   }
   if (h->fuse && enclayer_supported(h->prec, d, w.heads)) {
     EncLayerParams q = enc_params(c, n, w, x, Lk, lpad, text, pool);

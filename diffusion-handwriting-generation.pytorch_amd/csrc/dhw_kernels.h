@@ -103,10 +103,10 @@ struct EncLayerParams {
   const float *b_q1, *b_d1, *b_qkv2, *b_d2, *b_f1, *b_f2;
   const float *pb_q1, *pb_qk2;                     // PE·W tables [>=Lk][d], [>=Lk][2d]
   const float* film; long film_bs; int film_tot; int f1, f2, f3;
-  const void* k1; const void* vt1; int lpadT;      // text keys [B*Lt, d], values [B][d][lpadT]
+  const void* k1; const void* vt1; int lpadT;      // text keys [B*Lt, d]; values: bf16 kernels v1 [B*Lt, d] (rows, like k1), fp32 V^T [B][d][lpadT]
   const int64_t* text;                             // key padding mask source [B, Lt] (0 = pad)
   void* x2;                                        // [B*Lk, d]     written by enc_a, read by enc_bc
-  void* qk2; void* vt2; int lpadX;                 // [B*Lk, 2d], [B][d][lpadX]
+  void* qk2; void* vt2; int lpadX;                 // bf16 kernels: [q2 | k2 | v2] rows [B*Lk, 3d] (vt2 unused); fp32: [B*Lk, 2d] and V^T [B][d][lpadX]
   void* out; void* pool;                           // [B*Lk, d], optional [B*Lk/2, d]
   int bm_min;                                      // 0, or the smallest row tile to use (32 when enc_bc chains into a pooled layer)
   int dbg;                                         // diagnostics only: bit0 = skip the attention stage (a = q)
@@ -197,7 +197,7 @@ struct TextLayerParams {
   const void* w_kv; const float* b_kv;       // stacked K|V projection of the cross attention [2d x d]
   const float* pb_k1;     // PE·Wk table [>= Lt][d]
   void* k1;               // [n][Lt][d]
-  void* vt1; int lpadT;   // [n][d][lpadT], keys contiguous
+  void* vt1; int lpadT;   // v1 [n][Lt][d], rows like k1 (lpadT unused)
 };
 bool textside_supported(int prec, int Lt, int S5, int dt);
 hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st);

@@ -123,8 +123,9 @@ struct ParamStage {
 template <typename T> constexpr bool enc_plds() { return sizeof(T) == 2; }
 template <typename T, int DM> constexpr size_t enc_a_param_bytes() { return enc_plds<T>() ? (size_t)7 * DM * sizeof(float) : 0; }
 
-// LDS regions of the enc_a stages.  XR and QR are [BM][DM] tiles (row stride tile_stride(DM)); VS is the staging area of the
-// transposed v2 tile (DM rows of BM keys), free to overlay XR / QR; KT / VT hold one 32-key block of text keys / values.
+// LDS regions of the enc_a stages.  XR and QR are [BM][DM] tiles (row stride tile_stride(DM)); KT / VT hold one 32-key block of
+// text keys / values (bf16: both [keys][DM]; fp32 parity mode: V^T [DM][keys]); VS (fp32 only) is the staging area of the
+// transposed v2 tile (DM rows of BM keys), free to overlay XR / QR.
 struct EncALds {
   char* XR;     // x, later x2
   char* QR;     // q1, later a1
@@ -135,7 +136,11 @@ struct EncALds {
   float* PL;    // parameter block (enc_a_param_bytes), bf16 kernels
 };
 template <typename T, int DM, int BM>
-constexpr size_t enc_a_text_kv_bytes() { return (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + OPAD<T>); }   // (V^T row pad: attn_core.h)
+constexpr size_t enc_a_text_kv_bytes() {
+  return sizeof(T) == 2 ? (size_t)2 * 32 * tile_stride<T>(DM) : (size_t)32 * tile_stride<T>(DM) + (size_t)DM * (32 * sizeof(T) + OPAD<T>);
+}
+// row stride (elements) of the layer's [q2 | k2 (| v2)] buffer: the bf16 kernels keep v2 beside q2 / k2, row-major (attn_core.h)
+template <typename T, int DM> constexpr int qkv_stride() { return sizeof(T) == 2 ? 3 * DM : 2 * DM; }
 
 // enc_a for the BM-row tile [m0, m0+BM) of sample b, of which the first rows_valid rows are this workgroup's to write.
 // p.x == null: the x tile is already in m.XR (written by the caller's previous stage, behind a barrier) — this is how a
@@ -173,13 +178,15 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   // x tile, first block of text keys and of text values (usually all of them): every load is requested before the first
   // LDS store, so the three tiles cost one memory round trip together; its latency hides behind nothing (the q1 GEMM
   // needs x), the K / V tiles are only needed after q1.
-  constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = KBC * ES + OPAD<T>;
+  constexpr bool VROW = sizeof(T) == 2;   // V tiles [keys][channels] (bf16) or V^T [channels][keys] (fp32), attn_core.h
+  constexpr int KBC = 32, SKC = tile_stride<T>(DM), SVC = VROW ? SKC : KBC * ES + OPAD<T>;
   constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBC / EPV;
-  constexpr int UX = (BM * CPR + 511) / 512, UK = (KBC * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
+  constexpr int UX = (BM * CPR + 511) / 512, UK = (KBC * CPR + 511) / 512, UV = VROW ? UK : (DM * PPR + 511) / 512;
+  constexpr int QKS = qkv_stride<T, DM>();
   char* KT = m.KT;
   char* VT = m.VT;
   const T* k1s = reinterpret_cast<const T*>(p.k1) + (size_t)b * p.Lt * DM;
-  const T* v1s = reinterpret_cast<const T*>(p.vt1) + (size_t)b * DM * p.lpadT;
+  const T* v1s = reinterpret_cast<const T*>(p.vt1) + (VROW ? (size_t)b * p.Lt * DM : (size_t)b * DM * p.lpadT);   // v1 [Lt][DM] / V^T [DM][lpadT]
   constexpr bool PLDS = enc_plds<T>();
   const float* PL = m.PL;   // [b_q1 | b_d1 | gamma1 | beta1 | b_qkv2 x 3], DM floats each
   {
@@ -196,15 +203,23 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
                                                 return reinterpret_cast<const uint4*>(xs + (size_t)(b * p.Lk + (m0 + r < p.Lk ? m0 + r : p.Lk - 1)) * DM + cc * EPV); });
     ck.load(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
                                                return reinterpret_cast<const uint4*>(k1s + (size_t)(r < p.Lt ? r : p.Lt - 1) * DM + cc * EPV); });
-    cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
-                                              return reinterpret_cast<const uint4*>(v1s + (size_t)ch * p.lpadT + ((part + 1) * EPV <= p.lpadT ? part * EPV : 0)); });
+    if constexpr (VROW)
+      cv.load(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                                 return reinterpret_cast<const uint4*>(v1s + (size_t)(r < p.Lt ? r : p.Lt - 1) * DM + cc * EPV); });
+    else
+      cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                                                return reinterpret_cast<const uint4*>(v1s + (size_t)ch * p.lpadT + ((part + 1) * EPV <= p.lpadT ? part * EPV : 0)); });
     if (p.x)
       cx.store(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(XR + r * S + cc * 16); },
                [&](int id) { return m0 + id / CPR < p.Lk; });
     ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); },
              [&](int id) { return id / CPR < p.Lt; });
-    cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
-                [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
+    if constexpr (VROW)
+      cv.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(VT + r * SVC + cc * 16); },
+               [&](int id) { return id / CPR < p.Lt; });
+    else
+      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
+                  [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
     if constexpr (PLDS) cp.template store<DM>(m.PL, tid);
   }
   const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
@@ -234,8 +249,8 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
-        store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc[i][j] + ep.bias[i] + pb[i][j]);
+      for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
+    store_tiles<T, NT, MT>(lane, QR, S, row0, n0, acc);
     ENC_STAMP(9);
   }
   lds_barrier();
@@ -263,10 +278,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       if (kb) pad.load(lane, trow, kb, p.Lt);
       const unsigned padbits = pad.bits();
       if (kb) {
-        attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, p.lpadT, DM, kb, p.Lt, tid, 512);
+        attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, VROW ? DM : p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
       }
-      attn_units<T, KBC, true, UMAX>(lane, qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
+      attn_units<T, KBC, true, UMAX>(lane, qf, KT, SK, VT, SV, hs, HS, H, kb, padbits, p.Lt, mr, lr, o);
       if (kb + KBC < p.Lt) lds_barrier();   // the staging tiles are rewritten by the next block (after the last one the
                                              // barrier behind the a1 store below does)
     }
@@ -276,10 +291,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       float l = lr[u];
       l = xg_sum(l);
       const float inv = 1.0f / l;
-      if (h < H) {
+      if (h < H) {   // (wave-uniform)
         T* dst = reinterpret_cast<T*>(QR + (rg * 16 + l15) * S) + h * 64 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
+        store_pair(lane, dst, dst + 16, o[u][0] * inv, o[u][1] * inv);
+        store_pair(lane, dst + 32, dst + 48, o[u][2] * inv, o[u][3] * inv);
       }
     }
   }
@@ -306,15 +321,15 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
     ENC_STAMP(11);
     if (act) {
+      // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago).  A 16-byte paired store covers the
+      // partner lane's 4 channels too; its data depends, through the lane swap, on both lanes' reads of x, so no store of a
+      // pair is issued ahead of them.
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int r = row0 + j * 16 + l15;
-          T* xp = reinterpret_cast<T*>(XR + r * S) + n0 + 16 * i;
-          const f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(xp);
-          store4(xp, v);   // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago)
-        }
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(reinterpret_cast<const T*>(XR + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
+      store_tiles<T, NT, MT>(lane, XR, S, row0, n0, acc);
     }
   }
   lds_barrier();
@@ -323,6 +338,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 
   // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
   // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
+  // bf16: all three chunks are rows of the [.., 3 DM] buffer; fp32: v2 goes out transposed (V^T [DM][lpadX]).
 #pragma unroll 1
   for (int chunk = 0; chunk < 3; ++chunk) {
     int opaque = 0;
@@ -330,6 +346,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     f32x4 acc[NT][MT];
     acc_zero(acc);
     f32x4 pb[NT][MT];
+    const bool rows_out = chunk < 2 || VROW;   // this chunk is written as rows
     if (act) {
       if constexpr (!PLDS) ep.load_bias(p.b_qkv2 + chunk * DM, n0 + opaque);
       if (chunk < 2) {
@@ -338,36 +355,41 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #pragma unroll
           for (int j = 0; j < MT; ++j)
             pb[i][j] = *reinterpret_cast<const f32x4*>(p.pb_qk2 + (unsigned)((m0 + row0 + j * 16 + l15) * 2 * DM + chunk * DM + n0 + 16 * i + opaque));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j) pb[i][j] = (f32x4){0, 0, 0, 0};
       }
       ring.template run_s<MT, KC>(acc, xop + opaque, S, KC);
       ENC_STAMP(12 + chunk);
       if constexpr (PLDS) ep.lds_bias(PL + (4 + chunk) * DM, n0 + opaque);
       if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane);
     }
-    if (chunk < 2 && MT == 1) {
+    if (rows_out && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
       const int r = row0 + l15;
       if (act && r < rows_valid) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * 2 * DM + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
+          store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * QKS + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
       }
       ENC_STAMP(5 + chunk);
       continue;
     }
-    lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V) is free: every wave is past its readers
-    if (chunk < 2) {
-      // q2 / k2 chunk -> LDS tile [row][DM] -> coalesced rows of qk2 [.., 2*DM]
+    lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V^T) is free: every wave is past its readers
+    if (rows_out) {
+      // q2 / k2 (/ v2) chunk -> LDS tile [row][DM] -> coalesced rows of the [.., QKS] buffer
       if (act) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < MT; ++j)
-            store4(reinterpret_cast<T*>(QR + (row0 + j * 16 + l15) * S) + n0 + 16 * i + opaque, acc[i][j] + ep.bias[i] + pb[i][j]);
+          for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
+        store_tiles<T, NT, MT>(lane, QR, S, row0, n0 + opaque, acc);
       }
       lds_barrier();
-      tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * 2 * DM + chunk * DM, 2 * DM, rows_valid, DM, tid, 512);
-    } else {
+      tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);
+    } else if constexpr (!VROW) {
       // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2
       constexpr int SV = BM * ES + 16;
       char* VS = m.VS;
@@ -400,4 +422,3 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     ENC_STAMP(5 + chunk);
   }
 }
-

@@ -5,6 +5,13 @@
 
 namespace {
 
+#ifndef DHW_RING384
+#define DHW_RING384 24   // weight fragments in flight per wave in the d = 384 enc_bc stages (experiments: -DDHW_RING384=n)
+#endif
+#ifndef DHW_RINGD384
+#define DHW_RINGD384 8    // ... and the deepest ring (k-chunks) they may use
+#endif
+
 
 
 #define STAMP(slot) ENC_STAMP(slot)
@@ -38,7 +45,9 @@ DHW_DEV void enc_a_tile(const P& p, const int b, const int m0, char* smem) {
 // profiles/r03_head_enclayer_stage_stamps.log, d = 192: staged 2.7 / 2.0 us, computed 3.3 / 3.3 us.)
 // fp32 parity mode: single-buffered 32-key blocks (its tiles are twice as wide).
 template <typename T, int DM, int BM>
-constexpr size_t self_att_bytes(int kbs, int nbuf, int vpad = 16) { return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (size_t)DM * (kbs * sizeof(T) + vpad)); }
+constexpr size_t self_att_bytes(int kbs, int nbuf, int vpad = 16) {   // a2 tile + nbuf x (K tile + V tile: bf16 [keys][DM] like K, fp32 V^T [DM][keys])
+  return (size_t)BM * tile_stride<T>(DM) + nbuf * ((size_t)kbs * tile_stride<T>(DM) + (sizeof(T) == 2 ? (size_t)kbs * tile_stride<T>(DM) : (size_t)DM * (kbs * sizeof(T) + vpad)));
+}
 template <typename T, int DM, int BM>
 constexpr int self_kbs() { return sizeof(T) == 2 ? 64 : 32; }
 template <typename T, int DM, int BM>
@@ -80,7 +89,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  constexpr int RING = sizeof(T) == 4 ? 12 : (DM == 384 ? 15 : 24);   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
+  constexpr int RING = sizeof(T) == 4 ? 12 : (DM == 384 ? DHW_RING384 : 24);   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
@@ -98,7 +107,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   const char* op1 = R1 + (row0 + l15) * S + g * 8 * ES;
   const char* op3 = R3 + (row0 + l15) * S + g * 8 * ES;
 
-  WRing<T, NT, RING> ring;
+  WRing<T, NT, RING, (DM == 384 ? DHW_RINGD384 : 8)> ring;
   EpiParams<NT> ep;
   constexpr bool PLDS = enc_plds<T>(), PLFIX = bc_params_fixed<T, DM, BM>();
   float* PL = reinterpret_cast<float*>(smem + lds_bc_tiles<T, DM, BM>());   // (PLFIX; else chosen behind the attention loop)
@@ -111,29 +120,39 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   if (!(p.dbg & 1)) {  // ---- self attention over all Lk rows of the sample (K/V staged in LDS, 64 keys per block) -> a2 in LDS
     constexpr int RG = BM / 16, HS = 8 / RG, UMAX = (H + HS - 1) / HS, KBS = self_kbs<T, DM, BM>();
     constexpr bool DB = self_db<T, DM, BM>();
-    constexpr int SK = tile_stride<T>(DM), SV = KBS * ES + self_vpad<T, DM, BM>();
-    constexpr int BUFB = KBS * SK + DM * SV;   // one staged block: K tile, then V^T tile
+    constexpr bool VROW = sizeof(T) == 2;   // V tile [keys][DM] read with the transposing LDS read (bf16) or V^T [DM][keys] (fp32): attn_core.h
+    constexpr int SK = tile_stride<T>(DM), SV = VROW ? SK : KBS * ES + self_vpad<T, DM, BM>();
+    constexpr int BUFB = KBS * SK + (VROW ? KBS * SV : DM * SV);   // one staged block: K tile, then V tile
+    constexpr int QKS = qkv_stride<T, DM>();
     const int rg = wave % RG, hs = wave / RG;
     const T* qk = reinterpret_cast<const T*>(p.qk2);
-    const T* ksrc = qk + (size_t)b * p.Lk * 2 * DM + DM;
-    const T* vsrc = reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX;
+    const T* ksrc = qk + (size_t)b * p.Lk * QKS + DM;
+    const T* vsrc = VROW ? ksrc + DM : reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX;
     constexpr int EPV = 16 / ES, CPR = DM / EPV, PPR = KBS / EPV;
-    constexpr int UK = (KBS * CPR + 511) / 512, UV = (DM * PPR + 511) / 512;
+    constexpr int UK = (KBS * CPR + 511) / 512, UV = VROW ? UK : (DM * PPR + 511) / 512;
     CopyRegs<UK> ck;
     CopyRegs<UV> cv;
     // K rows [kb, kb + KBS) x DM channels and V^T rows [0, DM) x keys [kb, kb + KBS): requested at clamped (valid) addresses;
     // K rows at or past Lk and V^T pieces past lpadX are zero-filled by the store
     auto request = [&](int kb) {
       ck.load(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
-                                                 return reinterpret_cast<const uint4*>(ksrc + (size_t)min(kb + r, p.Lk - 1) * 2 * DM + cc * EPV); });
-      cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
-                                                return reinterpret_cast<const uint4*>(vsrc + (size_t)ch * p.lpadX + (kb + (part + 1) * EPV <= p.lpadX ? kb + part * EPV : 0)); });
+                                                 return reinterpret_cast<const uint4*>(ksrc + (size_t)min(kb + r, p.Lk - 1) * QKS + cc * EPV); });
+      if constexpr (VROW)
+        cv.load(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
+                                                   return reinterpret_cast<const uint4*>(vsrc + (size_t)min(kb + r, p.Lk - 1) * QKS + cc * EPV); });
+      else
+        cv.load(DM * PPR, tid, 512, [&](int id) { const int ch = id / PPR, part = id - ch * PPR;
+                                                  return reinterpret_cast<const uint4*>(vsrc + (size_t)ch * p.lpadX + (kb + (part + 1) * EPV <= p.lpadX ? kb + part * EPV : 0)); });
     };
     auto commit = [&](int kb, char* KT, char* VT) {
       ck.store(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SK + cc * 16); },
                [&](int id) { return kb + id / CPR < p.Lk; });
-      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SV, part, v); },
-                  [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
+      if constexpr (VROW)   // (V rows at or past Lk are zero: their softmax weights are exactly 0, the products must stay finite)
+        cv.store(KBS * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(VT + r * SV + cc * 16); },
+                 [&](int id) { return kb + id / CPR < p.Lk; });
+      else
+        cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SV, part, v); },
+                    [&](int id) { return kb + (id % PPR + 1) * EPV <= p.lpadX; });
     };
     Frag<T> qf[UMAX][2];
     float mr[UMAX], lr[UMAX];
@@ -141,7 +160,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
       const int h = hs + u * HS;
-      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * 2 * DM + (h < H ? h : 0) * 64 + 8 * g;
+      const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * QKS + (h < H ? h : 0) * 64 + 8 * g;
       qf[u][0] = frag_load(qrow);
       qf[u][1] = frag_load(qrow + 32);
       mr[u] = -INFINITY;
@@ -162,7 +181,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       char* KN = R2 + (DB && !(ib & 1) ? BUFB : 0);   // where the next block goes
       if (DB && more) request(kb + KBS);
       if (ib < 3) STAMP(26 + 2 * ib);
-      attn_units<T, KBS, false, UMAX>(lane, qf, KT + l15 * SK, SK, VT + l15 * SV, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
+      attn_units<T, KBS, false, UMAX>(lane, qf, KT, SK, VT, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
       if (ib < 3) STAMP(27 + 2 * ib);
       if (more) {
         if (!DB) {          // single buffer: every wave must be past its reads before the tiles are rewritten
@@ -189,10 +208,10 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       float l = lr[u];
       l = xg_sum(l);
       const float inv = 1.0f / l;
-      if (h < H) {
+      if (h < H) {   // (wave-uniform)
         T* dst = reinterpret_cast<T*>(R1 + (rg * 16 + l15) * S) + h * 64 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) store4(dst + 16 * t, o[u][t] * inv);
+        store_pair(lane, dst, dst + 16, o[u][0] * inv, o[u][1] * inv);
+        store_pair(lane, dst + 32, dst + 48, o[u][2] * inv, o[u][3] * inv);
       }
     }
   }
@@ -240,17 +259,14 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
     WST(7);
     if (act) {
+      // x3 -> R2, SiLU(x3) -> R1: whole-tile-group SiLU and 16-byte paired stores (epilogue.h)
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int r = row0 + j * 16 + l15;
-          f32x4 v = acc[i][j] * ep.gam[i] + ep.bet[i];
-          store4(reinterpret_cast<T*>(R2 + r * S) + n0 + 16 * i, v);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
-          store4(reinterpret_cast<T*>(R1 + r * S) + n0 + 16 * i, v);
-        }
+        for (int j = 0; j < MT; ++j) acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i];
+      store_tiles<T, NT, MT>(lane, R2, S, row0, n0, acc);
+      silu_tiles2<T, NT, MT>(acc);
+      store_tiles<T, NT, MT>(lane, R1, S, row0, n0, acc);
     }
   }
   WST(8);
@@ -276,12 +292,9 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          f32x4 v = acc[i][j] + ep.bias[i];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
-          store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v);
-        }
+        for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
+      silu_tiles2<T, NT, MT>(acc);
+      store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc);
     }
     WST(12 + 6 * hh);
     lds_barrier();
@@ -313,8 +326,8 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
-        store4(reinterpret_cast<T*>(R3 + (row0 + j * 16 + l15) * S) + n0 + 16 * i, acc2[i][j] * ep.gam[i] + ep.bet[i]);
+      for (int j = 0; j < MT; ++j) acc2[i][j] = acc2[i][j] * ep.gam[i] + ep.bet[i];
+    store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc2);
   }
   lds_barrier();
   const int rows_valid = min(BM, p.Lk - m0);
@@ -365,8 +378,8 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
       for (int i = 0; i < NTN; ++i)
 #pragma unroll
-        for (int j = 0; j < MTN; ++j)
-          store4(reinterpret_cast<T*>(XN + (j * 16 + l15) * SN) + nn0 + 16 * i, acc[i][j] + epd.bias[i]);
+        for (int j = 0; j < MTN; ++j) acc[i][j] += epd.bias[i];
+      store_tiles<T, NTN, MTN>(lane, XN, SN, 0, nn0, acc);
     }
     lds_barrier();
     const int m02 = m0 / 2, rows2 = rows_valid / 2;

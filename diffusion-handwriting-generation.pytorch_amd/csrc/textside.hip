@@ -312,9 +312,9 @@ template <typename T, int DMO, int OCC = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 * OCC))) void text_layer_kernel(const TextLayerParams p) {
   constexpr int ES = sizeof(T), DI = 384, BM = 32, KCI = DI / 32, KCO = DMO / 32;
   constexpr int WN = (DMO % 128 == 0) ? 8 : 6, NT = DMO / WN / 16, MT = BM / 16;
-  constexpr int SI = tile_stride<T>(DI), SO = tile_stride<T>(DMO), SVT = BM * ES + 16;
+  constexpr int SI = tile_stride<T>(DI), SO = tile_stride<T>(DMO);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* XS = smem;                       // SiLU(text_out) [BM][384]; later the k1 / transposed v1 staging tile
+  char* XS = smem;                       // SiLU(text_out) [BM][384]; later the k1 / v1 staging tile
   char* TL = XS + BM * SI;               // tl [BM][DMO]
   float* red = reinterpret_cast<float*>(TL + BM * SO);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
@@ -393,7 +393,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
     lds_barrier();
     tile_copy_out<T>(XS, SO, reinterpret_cast<T*>(p.k1) + (size_t)pair * p.Lt * DMO, DMO, p.Lt, DMO, tid, 512);
   }
-  {  // ---- v1 = Wv tl + bv (no PE: model.py:46), key-contiguous, zero past the tokens
+  {  // ---- v1 = Wv tl + bv (no PE: model.py:46) -> coalesced rows, like k1 (the cross-attention reads V^T with the transposing LDS
+     // read: attn_core.h)
     f32x4 acc[NT][MT];
     acc_zero(acc);
     if (act) {
@@ -405,28 +406,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          const int key = j * 16 + l15;
-          const f32x4 v = acc[i][j] + ep.bias[i];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) *reinterpret_cast<T*>(XS + (n0 + 16 * i + k) * SVT + key * ES) = from_f<T>(key < p.Lt ? v[k] : 0.f);
-        }
+        for (int j = 0; j < MT; ++j) store4(reinterpret_cast<T*>(XS + (j * 16 + l15) * SO) + n0 + 16 * i, acc[i][j] + ep.bias[i]);
     }
     lds_barrier();
-    constexpr int KPP = 16 / ES, PPR = BM / KPP;   // keys per 16-byte piece, pieces per channel row
-    T* vt = reinterpret_cast<T*>(p.vt1) + (size_t)pair * DMO * p.lpadT;
-    for (int id = tid; id < DMO * PPR; id += 512) {
-      const int ch = id / PPR, part = id - ch * PPR;
-      if ((part + 1) * KPP <= p.lpadT)
-        *reinterpret_cast<uint4*>(vt + (size_t)ch * p.lpadT + part * KPP) = *reinterpret_cast<const uint4*>(XS + ch * SVT + part * 16);
-    }
+    tile_copy_out<T>(XS, SO, reinterpret_cast<T*>(p.vt1) + (size_t)pair * p.Lt * DMO, DMO, p.Lt, DMO, tid, 512);
   }
 }
 
 constexpr size_t text_style_lds() { return (size_t)80 * tile_stride<bf16_t>(384) + (size_t)384 * (80 * 2 + 16) + (size_t)32 * tile_stride<bf16_t>(384) + 2 * 8 * 32 * sizeof(float); }
 template <int DMO>
 constexpr size_t text_layer_lds() {
-  return std::max((size_t)32 * tile_stride<bf16_t>(384), (size_t)DMO * (32 * 2 + 16)) + (size_t)32 * tile_stride<bf16_t>(DMO) + 2 * 8 * 32 * sizeof(float);
+  return (size_t)32 * tile_stride<bf16_t>(384) + (size_t)32 * tile_stride<bf16_t>(DMO) + 2 * 8 * 32 * sizeof(float);
 }
 
 }  // namespace

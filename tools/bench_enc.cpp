@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     p.film = (float*)dev_rand(1 << 20, true); p.film_bs = 0; p.film_tot = 9280; p.f1 = 0; p.f2 = 384; p.f3 = 768;
     p.k1 = dev_rand((size_t)(B * Lt + 128) * d * 2); p.vt1 = dev_rand((size_t)(B * d + 128) * lpadT * 2); p.lpadT = lpadT;
     p.text = nullptr;
-    p.x2 = dev_rand(rows * d * 2); p.qk2 = dev_rand(rows * 2 * d * 2); p.vt2 = dev_rand((size_t)(B * d + 128) * lpadX * 2); p.lpadX = lpadX;
+    p.x2 = dev_rand(rows * d * 2); p.qk2 = dev_rand(rows * 3 * d * 2); p.vt2 = dev_rand((size_t)(B * d + 128) * lpadX * 2); p.lpadX = lpadX;
     p.out = dev_rand(rows * d * 2); p.pool = nullptr;
     p.stamps = stamps;
     {  // realistic order: enc_a writes qk2 / vt2 / x2, enc_bc reads them straight after (timed per launch with events)

@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   p.pb_qk2 = (float*)dev_rand((size_t)(Lk + 128) * 2 * d * 4, true);
   p.film = (float*)dev_rand(1 << 20, true); p.film_bs = 0; p.film_tot = 9280; p.f1 = 0; p.f2 = 384; p.f3 = 768;
   p.k1 = dev_rand((size_t)(B * Lt + 128) * d * 2); p.vt1 = dev_rand((size_t)(B * d + 128) * lpadT * 2); p.lpadT = lpadT;
-  p.x2 = dev_rand(rows * d * 2); p.qk2 = dev_rand(rows * 2 * d * 2); p.vt2 = dev_rand((size_t)(B * d + 128) * lpadX * 2); p.lpadX = lpadX;
+  p.x2 = dev_rand(rows * d * 2); p.qk2 = dev_rand(rows * 3 * d * 2); p.vt2 = dev_rand((size_t)(B * d + 128) * lpadX * 2); p.lpadX = lpadX;
   p.out = dev_rand(rows * d * 2);
   p.stamps = stamps;
   for (int it = 0; it < 5; ++it) {
