@@ -172,7 +172,13 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   const char* xop = XR + (row0 + l15) * S + g * 8 * ES;
   const char* qop = QR + (row0 + l15) * S + g * 8 * ES;
 
-  WRing<T, NT> ring;
+#ifndef DHW_ENC_XSTREAM
+#define DHW_ENC_XSTREAM 0   // measured: 19.05 vs 18.98 ms per 60-step batch (profiles/r04_xstream_ab.log) -> off
+#endif
+  constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream with whole-stage rings (gemm_core.h, run_x)
+  constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream: a whole stage at d = 192 / 256, 8 of 12 chunks at d = 384
+  typedef WRing<T, NT, (XS ? XDE * NT : (sizeof(T) == 2 ? 24 : 12)), (XS ? XDE : 8)> RingT;
+  RingT ring;
   EpiParams<NT> ep;
   ENC_STAMP(0);
   // x tile, first block of text keys and of text values (usually all of them): every load is requested before the first
@@ -309,9 +315,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     f32x4 acc[NT][MT];
     acc_zero(acc);
     if (act) {
-      ring.template run_s<MT, KC>(acc, qop, S, KC);
+      if constexpr (XS) ring.template run_x<MT, KC, 0, KC>(acc, qop, S, KC, reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // + the q2 chunk's weights
+      else ring.template run_s<MT, KC>(acc, qop, S, KC);
       ENC_STAMP(10);
-      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
+      if constexpr (!XS) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
       if constexpr (PLDS) ep.lds(PL + DM, PL + 2 * DM, PL + 3 * DM, n0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -339,8 +346,9 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
   // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
   // bf16: all three chunks are rows of the [.., 3 DM] buffer; fp32: v2 goes out transposed (V^T [DM][lpadX]).
-#pragma unroll 1
-  for (int chunk = 0; chunk < 3; ++chunk) {
+  // (three calls of one body with compile-time chunk index and ring rotation: at d = 384 the rotation alternates, gemm_core.h)
+  auto qkv_chunk = [&](auto CHUNK_, auto ROT_) __attribute__((always_inline)) {
+    constexpr int chunk = decltype(CHUNK_)::value, ROTC = decltype(ROT_)::value;
     int opaque = 0;
     asm volatile("" : "+v"(opaque));
     f32x4 acc[NT][MT];
@@ -361,10 +369,15 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #pragma unroll
           for (int j = 0; j < MT; ++j) pb[i][j] = (f32x4){0, 0, 0, 0};
       }
-      ring.template run_s<MT, KC>(acc, xop + opaque, S, KC);
+      if constexpr (XS) {
+        if constexpr (chunk < 2) ring.template run_x<MT, KC, ROTC, KC>(acc, xop + opaque, S, KC, reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane);
+        else ring.template run_x<MT, KC, ROTC, 0>(acc, xop + opaque, S, KC);
+      } else {
+        ring.template run_s<MT, KC>(acc, xop + opaque, S, KC);
+      }
       ENC_STAMP(12 + chunk);
       if constexpr (PLDS) ep.lds_bias(PL + (4 + chunk) * DM, n0 + opaque);
-      if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane);
+      if constexpr (!XS) { if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); }
     }
     if (rows_out && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
@@ -375,7 +388,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
           store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * QKS + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
       }
       ENC_STAMP(5 + chunk);
-      continue;
+      return;
     }
     lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V^T) is free: every wave is past its readers
     if (rows_out) {
@@ -420,5 +433,9 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       }
     }
     ENC_STAMP(5 + chunk);
-  }
+  };
+  constexpr int RC0 = XS ? RingT::template next_rot<KC, 0>() : 0, RC1 = XS ? RingT::template next_rot<KC, RC0>() : 0, RC2 = XS ? RingT::template next_rot<KC, RC1>() : 0;
+  qkv_chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, RC0>{});
+  qkv_chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, RC1>{});
+  qkv_chunk(std::integral_constant<int, 2>{}, std::integral_constant<int, RC2>{});
 }

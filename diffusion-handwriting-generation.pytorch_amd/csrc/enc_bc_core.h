@@ -5,11 +5,12 @@
 
 namespace {
 
-#ifndef DHW_RING384
-#define DHW_RING384 24   // weight fragments in flight per wave in the d = 384 enc_bc stages (experiments: -DDHW_RING384=n)
-#endif
-#ifndef DHW_RINGD384
-#define DHW_RINGD384 8    // ... and the deepest ring (k-chunks) they may use
+// -DDHW_ENC_XSTREAM=1: the weight stream of the bf16 EncoderLayer stages refilled ACROSS stage boundaries (WRing::run_x: a stage's
+// first chunks are requested chunk by chunk during the previous stage's main loop, rings of a whole stage at d = 192 / 256 and
+// of 8 of the 12 chunks at d = 384) instead of as one burst behind the main loop.  Bit-identical; built on the per-wave
+// timelines' "fill" segments (0.9-1.9 kcycles per stage) and measured no faster: the burst is not additive.
+#ifndef DHW_ENC_XSTREAM
+#define DHW_ENC_XSTREAM 0   // measured: 19.05 vs 18.98 ms per 60-step batch (profiles/r04_xstream_ab.log) -> off
 #endif
 
 
@@ -89,7 +90,9 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   constexpr int ES = sizeof(T);
   constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
-  constexpr int RING = sizeof(T) == 4 ? 12 : (DM == 384 ? DHW_RING384 : 24);   // two live accumulator sets in the FFN stage: keep the ring within 256 VGPRs
+  constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream (gemm_core.h, run_x); the fp32 parity mode keeps run_s + fill_s
+  constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream
+  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : 24), RDMAX = XS ? XDE : 8;
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
@@ -107,7 +110,12 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   const char* op1 = R1 + (row0 + l15) * S + g * 8 * ES;
   const char* op3 = R3 + (row0 + l15) * S + g * 8 * ES;
 
-  WRing<T, NT, RING, (DM == 384 ? DHW_RINGD384 : 8)> ring;
+  WRing<T, NT, RING, RDMAX> ring;
+  // slot rotation of the stages (gemm_core.h): dense 0, FFN first halves ROT1, second halves ROT2 — and back to ROT1, so the loop over the
+  // two halves of the hidden layer stays rolled
+  typedef WRing<T, NT, RING, RDMAX> RingT;
+  constexpr int ROT1 = XS ? RingT::template next_rot<KC, 0>() : 0, ROT2 = XS ? RingT::template next_rot<KC, ROT1>() : 0;
+  static_assert(!XS || RingT::template next_rot<KC, ROT2>() == ROT1, "FFN loop rotation");
   EpiParams<NT> ep;
   constexpr bool PLDS = enc_plds<T>(), PLFIX = bc_params_fixed<T, DM, BM>();
   float* PL = reinterpret_cast<float*>(smem + lds_bc_tiles<T, DM, BM>());   // (PLFIX; else chosen behind the attention loop)
@@ -244,9 +252,14 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
           const int r = m0 + row0 + j * 16 + l15;
           res[i][j] = load4(reinterpret_cast<const T*>(p.x2) + (unsigned)((b * p.Lk + r) * DM + n0 + 16 * i));
         }
-      ring.template run_s<MT, KC>(acc, op1, S, KC);
-      WST(4);
-      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+      if constexpr (XS) {
+        ring.template run_x<MT, KC, 0, KC>(acc, op1, S, KC, reinterpret_cast<const T*>(p.w_f1) + wlane);   // + FFN half 0's first chunks
+        WST(4);
+      } else {
+        ring.template run_s<MT, KC>(acc, op1, S, KC);
+        WST(4);
+        ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+      }
       WST(5);
       if constexpr (PLDS) ep.lds(PL, PL + DM, PL + 2 * DM, n0);
 #pragma unroll
@@ -283,11 +296,13 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       f32x4 acc[NT][MT];
       acc_zero(acc);
       if constexpr (!PLDS) ep.load_bias(p.b_f1 + hh * DM, n0);
-      ring.template run_s<MT, KC>(acc, op1, S, KC);
+      // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: the next stage's weights
+      const T* w2 = reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8;
+      if constexpr (XS) ring.template run_x<MT, KC, ROT1, KC>(acc, op1, S, KC, w2, 2 * KC);
+      else ring.template run_s<MT, KC>(acc, op1, S, KC);
       WST(10 + 6 * hh);
       if constexpr (PLDS) ep.lds_bias(PL + (3 + hh) * DM, n0);
-      // K-slice [hh*DM, (hh+1)*DM) of W2 [DM][2*DM]: flies during the SiLU epilogue and the barrier
-      ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f2) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
+      if constexpr (!XS) ring.template fill_s<KC>(w2, 2 * KC);   // flies during the SiLU epilogue and the barrier
       WST(11 + 6 * hh);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
@@ -301,9 +316,15 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     WST(13 + 6 * hh);
     STAMP(20 + 2 * hh);
     if (act) {
-      ring.template run_s<MT, KC>(acc2, op3, S, KC);
-      WST(14 + 6 * hh);
-      if (hh == 0) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // FFN half 1
+      if constexpr (XS) {
+        if (hh == 0) ring.template run_x<MT, KC, ROT2, KC>(acc2, op3, S, KC, reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // + FFN half 1
+        else ring.template run_x<MT, KC, ROT2, 0>(acc2, op3, S, KC);
+        WST(14 + 6 * hh);
+      } else {
+        ring.template run_s<MT, KC>(acc2, op3, S, KC);
+        WST(14 + 6 * hh);
+        if (hh == 0) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + (size_t)DM * DM + wlane);   // FFN half 1
+      }
     }
     if (hh == 0) lds_barrier();   // R3 is rewritten by the next half (after the last one the LayerNorm barrier below does)
     WST(15 + 6 * hh);

@@ -173,6 +173,49 @@ struct WRing {
 #pragma unroll
     for (int j = 0; j < KT_ - G * D; ++j) step(j % D, G * D + j + D < KT_, G * D + j + D);
   }
+
+  // ---- the stream across a stage boundary (the EncoderLayer kernels' short stages: KT_ <= 12 chunks, fully unrolled).
+  // run_s + fill_s issue the next stage's first fragments only AFTER the main loop, as one burst: a wave is blocked while its
+  // vector-memory instructions queue for the CU's L1 return path (64 B/clk for all 8 waves), so stage time = main loop + burst
+  // (0.9-1.9 kcycles of a 4-7 kcycle stage: profiles/r04_encbc_wave_timeline_*.log, "fill") + epilogue.  Here every ring slot
+  // is refilled the moment its chunk is consumed, with the stream's NEXT chunk whichever stage that belongs to: this stage's
+  // chunk s + DE while there is one, then chunks 0 .. of the next stage (nbase / nkts).  The path then carries one continuous
+  // stream under the MFMAs and the burst disappears; the next stage finds its first chunks exactly where fill_s would have
+  // put them, rotated by ROT: chunk c of a stage sits in slot (c + ROT) mod DE, DE = min(D, KT_), and the next stage's
+  // rotation is next_rot<KT_, ROT>().  Same loads, same MFMA order per accumulator: bit-identical results.
+  template <int KT_> static constexpr int eff_depth() { return D < KT_ ? D : KT_; }
+  template <int KT_, int ROT> static constexpr int next_rot() { return (ROT + KT_) % eff_depth<KT_>(); }
+  // KTN_: the next stage's chunk count (0 = none: the ring drains).  Requires eff_depth<KTN_>() == eff_depth<KT_>() (or KTN_ == 0).
+  template <int MT, int KT_, int ROT, int KTN_>
+  DHW_DEV void run_x(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC, const T* __restrict__ nbase = nullptr, int nkts = 0) {
+    constexpr int ES = sizeof(T), DE = eff_depth<KT_>();
+    static_assert(KTN_ == 0 || eff_depth<KTN_>() == DE, "the next stage must use the same ring depth");
+    const int nKTS = nkts ? nkts : KTN_;
+    int aoff = 0, kc = 0;
+    const int tap_step = stride - (KC - 1) * 32 * ES;
+#pragma unroll
+    for (int s = 0; s < KT_; ++s) {
+      const int d = (s + ROT) % DE;
+      Frag<T> a[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], q[d][i], a[j]);
+      const int nx = s + DE;   // position in the concatenated stream that goes into the freed slot
+      if (nx < KT_) {
+        load_chunk(d, nx);
+      } else if (KTN_ != 0 && nx - KT_ < DE) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) q[d][i] = frag_load(nbase + ((size_t)i * nKTS + (nx - KT_)) * 512);
+      }
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    }
+    if (KTN_ != 0) { base = nbase; KT = KTN_; KTS = nKTS; }
+  }
 };
 
 // one-shot form: fill + run
