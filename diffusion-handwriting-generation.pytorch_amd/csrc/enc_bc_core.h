@@ -92,7 +92,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream (gemm_core.h, run_x); the fp32 parity mode keeps run_s + fill_s
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream
-  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : 24), RDMAX = XS ? XDE : 8;
+  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 && BM >= 32 ? 15 : 24)), RDMAX = XS ? XDE : 8;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill)
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
