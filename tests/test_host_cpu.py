@@ -159,3 +159,21 @@ def test_xcd_swizzle_is_a_bijection_with_contiguous_ranges_per_xcd():
         for x in range(min(8, nwg)):
             mine = sorted(ids[i] for i in range(x, nwg, 8))
             assert mine == list(range(mine[0], mine[0] + len(mine))), (nwg, x)
+
+
+def test_kernel_source_hash_covers_csrc():
+    """bench.py marks the committed PMC traffic figures stale when the sampler's kernel sources change: every file under csrc/
+    must be either hashed (SAMPLER_SOURCES) or explicitly listed as not part of the sampling path (NON_SAMPLER_SOURCES)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    d = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd", "csrc")
+    files = {f for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))}
+    assert not (bench.SAMPLER_SOURCES & bench.NON_SAMPLER_SOURCES)
+    unknown = files - bench.SAMPLER_SOURCES - bench.NON_SAMPLER_SOURCES
+    assert not unknown, f"csrc files in neither list of bench.py: {sorted(unknown)}"
+    missing = (bench.SAMPLER_SOURCES | bench.NON_SAMPLER_SOURCES) - files
+    assert not missing, f"bench.py lists csrc files that do not exist: {sorted(missing)}"
+    h1 = bench.kernel_source_hash()
+    assert len(h1) == 16 and h1 == bench.kernel_source_hash()
