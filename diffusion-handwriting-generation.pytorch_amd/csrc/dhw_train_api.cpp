@@ -2,6 +2,8 @@
 // kernels and the ConvBlock forward + backward built from the generic MFMA GEMM (forward and data-gradient
 // convolutions, the latter with transposed / tap-flipped packed weights) and the kernels of train.hip.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 
 #include <cstdarg>
 #include <cstdio>
@@ -118,13 +120,22 @@ int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* cons
                    float beta1, float beta2, float eps, float weight_decay, int step, float max_norm, float* grad_norm_out, void* hip_stream) {
   if (nbuf < 1 || !p || !g || !m || !v || !n || step < 1) return tfail(DHW_ERR_ARG, "dhw_train_adam: bad argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  // the squared-norm scalar: allocated once per calling thread and kept (a hipMalloc / hipFree pair and a stream
-  // synchronisation per update used to sit here; an error return between them leaked the allocation)
-  static thread_local float* sq_keep = nullptr;
+  // the squared-norm scalar: allocated once per DEVICE and kept for the life of the process (a hipMalloc / hipFree pair and a
+  // stream synchronisation per update used to sit here).  One scalar per device: calls on different streams of one device must
+  // not overlap, and the first call on a device allocates, so it must not be made under stream capture — dhw_train_adam_dev,
+  // which takes the scalar from the caller, is the form for graphs and concurrent streams (include/dhw_train.h).
+  static std::mutex sq_mu;
+  static std::map<int, float*> sq_by_device;
   float* sq = nullptr;
   if (max_norm > 0.f || grad_norm_out) {
-    if (!sq_keep) THIP(hipMalloc((void**)&sq_keep, sizeof(float)));
-    sq = sq_keep;
+    int dev = 0;
+    THIP(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lk(sq_mu);
+      float*& slot = sq_by_device[dev];
+      if (!slot) THIP(hipMalloc((void**)&slot, sizeof(float)));
+      sq = slot;
+    }
     THIP(hipMemsetAsync(sq, 0, sizeof(float), st));
     for (int i = 0; i < nbuf; ++i) THIP(launch_sqnorm(g[i], n[i], sq, st));
   }

@@ -31,17 +31,25 @@ def check_token_ids(text: torch.Tensor, seen: list | None = None) -> None:
     """The reference's ``nn.Embedding`` raises IndexError for an id outside [0, 73); the kernels would clamp it.  One
     reduction + one host read — a blocking device sync when ``text`` lives on the GPU, so a caller that samples the same
     prompt tensor repeatedly passes ``seen`` (a small list it owns): a tensor object that was validated before and has not
-    been written since (same object, same ``_version``) is not read again, and the next sampling call's launch does not wait
-    for the previous one to drain.  The list holds the validated tensors themselves, so their storage cannot be recycled
-    under a stale entry."""
+    been written since (same object, same storage, same ``_version``) is not read again, and the next sampling call's launch
+    does not wait for the previous one to drain.
+
+    Caveat of the cache (exact semantics need ``seen=None``, which ``forward`` uses): ``_version`` counts in-place torch
+    operations only — a write through ``.data``, through numpy memory shared with ``torch.from_numpy``, or by another library is
+    invisible to it, and an out-of-range id written that way is clamped by the kernels instead of raising.  The entries are
+    WEAK references (a validated prompt tensor is not kept alive, and a dead entry can never match a new tensor that reuses its
+    address: the comparison is on the live object)."""
+    import weakref
     if seen is not None:
-        for t, ver in seen:
-            if t is text and ver == text._version:
+        for ref, ptr, ver in seen:
+            t = ref()
+            if t is text and ptr == text.data_ptr() and ver == text._version:
                 return
     if text.numel() and bool(((text < 0) | (text >= VOCAB)).any()):
         raise IndexError(f"index out of range in self: token ids must lie in [0, {VOCAB})")
     if seen is not None:
-        seen.append((text, text._version))
+        seen[:] = [e for e in seen if e[0]() is not None]
+        seen.append((weakref.ref(text), text.data_ptr(), text._version))
         del seen[:-4]
 
 

@@ -26,9 +26,10 @@ from .train import Adam, _stream, _tcheck, allreduce_grads, get_alphas, loss_fn,
 _F = 4  # bytes per element
 
 
-# DHW_TRAIN_WGRAD_SIDE=1: weight-gradient GEMMs on the tape's side stream (parallel hipGraph branches beside the data-gradient
-# chain).  Measured slower (9.93 vs 9.12 ms per update, r3): the GEMMs already fill the CUs, the branches only interleave them.
-WGRAD_SIDE = os.environ.get("DHW_TRAIN_WGRAD_SIDE", "0") == "1"
+# (The weight-gradient GEMMs run on the main stream.  A second stream beside the data-gradient chain — rounds 2 and 3,
+# DHW_TRAIN_WGRAD_SIDE — measured slower (17.3 vs 15.1, later 9.93 vs 9.12 ms per update: the GEMMs already fill the CUs, parallel
+# graph branches only interleave them) and, once gradient buffers were handed from an op's output to its addend, raced with the
+# main stream's writes into those buffers; the switch and the side stream were removed in round 4.)
 # DHW_TRAIN_FUSE_DSILU=0: SiLU's backward as its own pass again instead of a factor in the consuming GEMM's data-gradient output (A/B)
 FUSE_DSILU = os.environ.get("DHW_TRAIN_FUSE_DSILU", "1") != "0"
 
@@ -57,17 +58,6 @@ def positional_encoding(length: int, dim: int, pos_factor: float) -> torch.Tenso
     return torch.cat((e.sin(), e.cos()), dim=-1).float()
 
 
-_SIDE = {}
-
-
-def side_stream(device) -> "torch.cuda.Stream":
-    """One long-lived second stream per device for the parameter-gradient work."""
-    key = torch.device(device).index or 0
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device)
-    return _SIDE[key]
-
-
 class Tape:
     """Forward ops append their backward closure; ``backward()`` replays them in reverse.  Every backward kernel ADDS into
     the input's gradient buffer (zero-initialised on first touch), which is how autograd's fan-in sums arise."""
@@ -78,14 +68,6 @@ class Tape:
         self.lib = _lib.lib()
         self.main = torch.cuda.current_stream(device)
         self.st = _stream(device)
-        # bias-gradient sums are off the critical path of the backward sweep: they run on a second stream, forked where their
-        # upstream gradient becomes ready and joined once at the end of backward().  (The weight-gradient GEMMs stay on the main
-        # stream: run beside the data-gradient chain they slowed the update from 15.1 to 17.3 ms — two GEMMs sharing the CUs
-        # lose more to L2 / LDS contention than the idle CUs of the small ones gain.)
-        self.side = side_stream(device)
-        self.side_st = C.c_void_p(self.side.cuda_stream)
-        self.forked = False
-        self.held = []
         self.steps = []
         self.launches = 0
         self.flops = 0          # algorithmic FLOPs of every GEMM issued (2 M N K per batch entry)
@@ -94,23 +76,8 @@ class Tape:
     def new(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
 
-    def fork(self, *tensors):
-        """Order the side stream after everything issued so far on the main one; the tensors it will read stay referenced
-        until the join (the allocator must not hand their memory to later main-stream work)."""
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        self.side.wait_event(ev)
-        self.forked = True
-        self.held.extend(tensors)
-
-    def join(self):
-        if self.forked:
-            self.main.wait_stream(self.side)
-            self.forked = False
-        self.held = []
-
     def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
-             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0, side=False,
+             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
              rowsum=None, addend=None, act_out=None, dsilu_of=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
@@ -132,7 +99,7 @@ class Tape:
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
                           act_out.data_ptr() if act_out is not None else None, addend.data_ptr() if addend is not None else None,
                           dsilu_of.data_ptr() if dsilu_of is not None else None, rowsum.data_ptr() if rowsum is not None else None)
-        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.side_st if side else self.st))
+        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
         self.launches += 1
         self.flops += 2 * M * N * K * nzo * nzi
 
@@ -147,8 +114,8 @@ class Tape:
             v.g = torch.empty_like(v.d)
         return v.g, 0
 
-    def call(self, fn, *args, side=False):
-        _tcheck(getattr(self.lib, fn)(*args, self.side_st if side else self.st))
+    def call(self, fn, *args):
+        _tcheck(getattr(self.lib, fn)(*args, self.st))
         self.launches += 1
 
     def _grad_to(self, v: "Var", dy: torch.Tensor):
@@ -202,10 +169,8 @@ class Tape:
                 else:
                     dx, acc = self.into(x)
                     self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)         # dx (+)= dy W
-            dW, db = W.grad(), b.grad() if b is not None else None     # (allocated / zeroed on the main stream, before the fork)
-            if WGRAD_SIDE:
-                self.fork(dy, x.d)
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, rowsum=db, side=WGRAD_SIDE)   # dW += dy^T x, db += column sums of dy
+            dW, db = W.grad(), b.grad() if b is not None else None
+            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, rowsum=db)   # dW += dy^T x, db += column sums of dy
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
@@ -234,19 +199,17 @@ class Tape:
             gco, gci, gt = dW.stride()
             fuse = merged and x.pre is not None    # x = SiLU(u): the merged data-gradient GEMM writes d u itself
             dx, acc = self.into(x.pre if fuse else x)
-            if WGRAD_SIDE:
-                self.fork(dy, x.d)
             # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
             if merged:
                 self.gemm(dy, 0, Cout, 1, W.d, 0, sco, sci, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
                           sbt=st, lr=L, dsilu_of=x.pre.d if fuse else None)
                 self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, gco, gci, Cout, Cin, R, acc=True, nzi=3, zc=(0, gt), b_shift=-1,
-                          b_z_shift=1, lr=L, rowsum=db, side=WGRAD_SIDE)                            # the taps as the inner batch index; db rides along
+                          b_z_shift=1, lr=L, rowsum=db)                            # the taps as the inner batch index; db rides along
             else:
                 for t in range(3):
                     self.gemm(dy, 0, Cout, 1, W.d, t * st, sco, sci, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)
                     self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, t * gt, gco, gci, Cout, Cin, R, acc=True, b_shift=t - 1, lr=L,
-                              rowsum=db if t == 1 else None, side=WGRAD_SIDE)
+                              rowsum=db if t == 1 else None)
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
@@ -452,7 +415,6 @@ class Tape:
         for step in reversed(self.steps):
             step()
         self.steps = []
-        self.join()
 
     def record(self, out: Var, fn):
         """fn runs in the backward sweep iff a gradient reached ``out``."""
@@ -468,7 +430,9 @@ class TrainModel:
         """``drop_rate``: the EncoderLayers' dropout (model.py:23; configs/best.yml trains with 0.0, the class default is 0.1).
         ``precision``: "fp32" — exact-f32 MFMA everywhere, the mode the gradient fixtures pin — or "bf16": mixed precision, every
         GEMM (Linear / Conv1d / attention, forward and backward) contracts bf16-rounded operands with fp32 accumulation; weights,
-        activations in memory, gradients, optimizer state and all non-GEMM arithmetic stay fp32."""
+        activations in memory, gradients, optimizer state and all non-GEMM arithmetic stay fp32 — with one exception: a bias
+        gradient is summed inside its layer's weight-gradient GEMM from the bf16-rounded dy tile (dhw_gemm_desc.rowsum), so it
+        carries the same operand rounding as that weight gradient (tests: the bf16 cases of the GEMM sweep)."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision

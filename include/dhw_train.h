@@ -33,7 +33,10 @@ int dhw_train_loss(const float* eps, const float* score_pred, const float* pen, 
                    int B, int L, float* out3, float* d_score, float* d_pen_pred, void* hip_stream);
 
 /* One optimizer step on `nbuf` flat parameter buffers: global-norm clip (max_norm <= 0: none) over ALL of them, then Adam.
- * p/g/m/v: arrays of device pointers, n: element counts; step = 1 for the first update (bias correction). */
+ * p/g/m/v: arrays of device pointers, n: element counts; step = 1 for the first update (bias correction).
+ * The squared gradient norm goes through ONE scratch scalar per device that the library allocates at the first call on that
+ * device and keeps: (a) that first call must not be made under stream capture, (b) calls on different streams of one device
+ * must not overlap.  dhw_train_adam_dev below has neither constraint (the caller owns the scalar). */
 int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
                    float* grad_norm_out /* device, 1 float, or NULL */, void* hip_stream);
@@ -96,7 +99,10 @@ typedef struct {
   const float* dsilu_of; /* NULL, or an array laid out as C: the product is multiplied by SiLU'(dsilu_of) before it is written / added — the
                             data gradient of a Linear / Conv1d whose input was SiLU(u) goes straight into du (no bias / addend with it) */
   float* rowsum;   /* NULL, or [M]: rowsum[m] += sum_k A(0,m,k) (batch z = 0 only) — the bias gradient of a Linear / Conv1d comes out
-                      of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum) */
+                      of its weight-gradient GEMM (A = dy^T) instead of a second pass over dy (dhw_op_colsum).  The sums are taken from
+                      the operand tile as staged for the MFMA: with bf16 = 1 that is dy ROUNDED to bf16 (fp32 accumulation), i.e. the
+                      bias gradient carries the same operand rounding as the weight gradient of its layer (relative 2^-9 per term,
+                      sqrt(K)-averaged); with bf16 = 0 it is exact fp32.  act_out / addend / dsilu_of are applied in fp32 either way. */
 } dhw_gemm_desc;
 
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);

@@ -123,6 +123,19 @@ def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
     for bad in ([[73]], [[-1, 3]], [[5, 1000]]):
         with pytest.raises(IndexError):
             check_token_ids(torch.tensor(bad))
+    # the per-prompt cache of validated tensors: same object + same version is not re-read, an in-place write is; entries are weak
+    seen = []
+    t = torch.tensor([[1, 2, 3]])
+    check_token_ids(t, seen)
+    check_token_ids(t, seen)
+    assert len(seen) == 1
+    t[0, 1] = 99                       # (bumps _version)
+    with pytest.raises(IndexError):
+        check_token_ids(t, seen)
+    del t
+    import gc
+    gc.collect()
+    assert all(ref() is None for ref, _, _ in seen)   # a validated prompt tensor is not kept alive by the cache
     m = dhg_amd.DiffusionModel(2)
     with pytest.raises(IndexError):    # checked before the device is touched
         m(torch.zeros(1, 8, 2), torch.tensor([[73]]), torch.ones(1, 1), torch.zeros(1, 14, 1280))
