@@ -21,33 +21,34 @@
 
 namespace {
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BMO = BM - 2;
+  constexpr int BMO = BM - 2 - 2 * TIGHT;
   const int tiles = (p.L + BMO - 1) / BMO;
   // XCD-aware workgroup id, the same sample -> XCD assignment in every fused kernel of the model: a sample's activations
   // are then handed from kernel to kernel inside one XCD's L2 (measured: a 98 KB tile written by the previous kernel on
   // the same XCD is read in 1.6 us, from another XCD in 3.8 us — tools/bench_handoff.cpp)
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-  convblock_body<T, BM, CO, NW, OCC, UPC, CH, CIN>(p, nx, bid / tiles, (bid % tiles) * BMO, smem);
+  convblock_body<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>(p, nx, bid / tiles, (bid % tiles) * BMO, smem);
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
   size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
   if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>() + enc_a_param_bytes<T, CO>());
   if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32)) || (CH != 0) != (nx != nullptr)) return hipErrorInvalidValue;
   if (CIN && (p.Cin != CIN || (UPC && p.up_cin != up_skip_width<UPC>()))) return hipErrorInvalidValue;
-  const int tiles = (p.L + BM - 3) / (BM - 2);
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
+  constexpr int BMO = BM - 2 - 2 * TIGHT;
+  const int tiles = (p.L + BMO - 1) / BMO;
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -68,6 +69,7 @@ hipError_t convblock_init() {
   // decoder blocks with the fused Upsample + skip_conv input stage
   A(bf16_t, 64, 128, 8, 1, 192, 0, 192); A(bf16_t, 128, 128, 8, 1, 192, 0, 192); A(bf16_t, 64, 192, 8, 1, 256, 0, 256);
   A(bf16_t, 64, 256, 8, 1, 384, 0, 384); A(bf16_t, 48, 256, 8, 1, 384, 0, 384);
+  A(bf16_t, 128, 128, 8, 1, 192, 0, 192, 1); A(bf16_t, 48, 256, 8, 1, 384, 0, 384, 1);   // ... writing BM - 4 rows per tile (convblock_core.h, TIGHT)
   // encoder blocks that continue into the next EncoderLayer's first half
   A(bf16_t, 64, 192, 8, 1, 0, 1, 128); A(bf16_t, 48, 256, 8, 1, 0, 1, 192); A(bf16_t, 64, 256, 8, 1, 0, 1, 192);
   A(float, 32, 128, 4); A(float, 32, 192, 4); A(float, 32, 256, 4);
@@ -89,13 +91,19 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
   static const bool rt = getenv("DHW_CONV_RT") && atoi(getenv("DHW_CONV_RT"));   // A/B: force the run-time-width variants
   if (p.up_h) {   // decoder block with the fused Upsample + skip_conv input stage (bf16 only)
     if (prec != PREC_BF16 || p.strokes || !p.up_w || !p.up_b || !p.up_low) return hipErrorInvalidValue;
+    // (BM - 4 output rows per tile where that needs no more tiles than BM - 2: the input stage then has no partial row tile)
+    static const bool tight_ok = !(getenv("DHW_CONV_TIGHT") && atoi(getenv("DHW_CONV_TIGHT")) == 0);
+    auto tight = [&](int bm) { return tight_ok && (p.L + bm - 5) / (bm - 4) == (p.L + bm - 3) / (bm - 2); };
     if (p.Cout == 128 && p.Cin == 192 && p.up_cin == 128) {
       const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
+      if (big && tight(128)) return launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 1>(p, st);
       return big ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192, 0, 192>(p, st);
     }
     if (p.Cout == 192 && p.Cin == 256 && p.up_cin == 192) return launch_t<bf16_t, 64, 192, 8, 1, 256, 0, 256>(p, st);
-    if (p.Cout == 256 && p.Cin == 384 && p.up_cin == 256)
+    if (p.Cout == 256 && p.Cin == 384 && p.up_cin == 256) {
+      if (use_bm48(p) && tight(48)) return launch_t<bf16_t, 48, 256, 8, 1, 384, 0, 384, 1>(p, st);
       return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 384, 0, 384>(p, st) : launch_t<bf16_t, 64, 256, 8, 1, 384, 0, 384>(p, st);
+    }
     return hipErrorInvalidValue;
   }
   if (prec == PREC_BF16) {

@@ -58,14 +58,20 @@ struct Epi {   // this lane's bias / FiLM gamma / beta for its NT channel tiles,
 template <int UPC> constexpr int up_skip_width() { return UPC == 384 ? 256 : UPC == 256 ? 192 : UPC == 192 ? 128 : 0; }   // model.py:169-175
 // The block for the BM-2-row tile at m0 of sample b, as a device function over the workgroup's LDS: the per-launch kernel
 // (convblock.hip) and the persistent per-step kernel (persist.hip) both run it.
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, typename P, typename X>
+// TIGHT = 1: the workgroup writes BM - 4 rows instead of BM - 2, so that the x rows it needs — its output rows plus the two
+// halo rows on each side of the two stacked 3-tap convolutions — are exactly BM: whole 16-row MFMA tiles.  With BM - 2 output
+// rows the fused decoder input stage (the block's largest GEMM: Upsample + skip_conv for BM + 2 rows) computes one more row tile
+// of which 2 rows are used: 4 tiles for 50 rows at BM = 48, 9 for 130 at BM = 128.  Chosen at launch when the row count of the
+// level needs the same number of tiles either way (L / 4 = 122: 3 tiles of 44 or of 46).  The h1 / h2 / output rows past the
+// BM - 4 valid ones are computed from whatever finite values follow the staged tiles in LDS and are never stored.
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, typename P, typename X>
 DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, char* smem) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr bool SK = CIN != 0;          // static contraction lengths
   constexpr int KT1 = 3 * CIN / 32;      // conv1 / conv_skip k-chunks when SK
   static_assert(UPC == 0 || CIN == 0 || CIN == UPC, "a fused input stage produces the block's own input width");
-  constexpr int BMO = BM - 2;            // output rows per workgroup
-  constexpr int RX = BM + 2;             // staged x rows: sample rows [m0-2, m0+BM)
+  constexpr int BMO = BM - 2 - 2 * TIGHT;   // output rows per workgroup
+  constexpr int RX = BMO + 4;               // staged x rows: sample rows [m0 - 2, m0 + BMO + 2)
   constexpr int C1 = CO / 2;             // conv1 output channels
   // Wave layouts (row groups x channel groups): stage 1 (conv1, C1 channels) and stages 2,3 (CO channels).
   // Every wave streams its OWN weight fragments from L2, so waves that differ only in their row group fetch the same

@@ -177,7 +177,11 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #endif
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream with whole-stage rings (gemm_core.h, run_x)
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream: a whole stage at d = 192 / 256, 8 of 12 chunks at d = 384
-  typedef WRing<T, NT, (XS ? XDE * NT : (sizeof(T) == 2 ? 24 : 12)), (XS ? XDE : 8)> RingT;
+#ifndef DHW_RINGA384
+#define DHW_RINGA384 24   // fragments in flight per wave in enc_a's d = 384 stages on 16-row tiles (experiments: 30 / 36 = a whole stage)
+#endif
+  constexpr int RINGA = sizeof(T) == 4 ? 12 : (DM == 384 && BM == 16 ? DHW_RINGA384 : 24);
+  typedef WRing<T, NT, (XS ? XDE * NT : RINGA), (XS ? XDE : (RINGA + NT - 1) / NT)> RingT;
   RingT ring;
   EpiParams<NT> ep;
   ENC_STAMP(0);

@@ -9,6 +9,9 @@ namespace {
 // first chunks are requested chunk by chunk during the previous stage's main loop, rings of a whole stage at d = 192 / 256 and
 // of 8 of the 12 chunks at d = 384) instead of as one burst behind the main loop.  Bit-identical; built on the per-wave
 // timelines' "fill" segments (0.9-1.9 kcycles per stage) and measured no faster: the burst is not additive.
+#ifndef DHW_RING384
+#define DHW_RING384 24   // weight fragments in flight per wave in enc_bc's d = 384 stages on 16-row tiles (15 in round 3; 30 / 36 = a whole stage: experiments)
+#endif
 #ifndef DHW_ENC_XSTREAM
 #define DHW_ENC_XSTREAM 0   // measured: 19.05 vs 18.98 ms per 60-step batch (profiles/r04_xstream_ab.log) -> off
 #endif
@@ -92,7 +95,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream (gemm_core.h, run_x); the fp32 parity mode keeps run_s + fill_s
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream
-  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 && BM >= 32 ? 15 : 24)), RDMAX = XS ? XDE : 8;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill)
+  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 ? (BM >= 32 ? 15 : DHW_RING384) : 24)), RDMAX = XS ? XDE : (RING + NT - 1) / NT;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill)
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
