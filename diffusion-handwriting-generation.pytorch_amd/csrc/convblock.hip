@@ -25,7 +25,7 @@ template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH =
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BMO = BM - 2 - 2 * TIGHT;
+  constexpr int BMO = TIGHT == 2 ? BM : BM - 2 - 2 * TIGHT;
   const int tiles = (p.L + BMO - 1) / BMO;
   // XCD-aware workgroup id, the same sample -> XCD assignment in every fused kernel of the model: a sample's activations
   // are then handed from kernel to kernel inside one XCD's L2 (measured: a 98 KB tile written by the previous kernel on
@@ -36,11 +36,11 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
 
 template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
-  size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0);
+  size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0, TIGHT == 2 ? BM + 16 : BM);
   if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>() + enc_a_param_bytes<T, CO>());
   if (lds > 160 * 1024 || (UPC && (p.Cin != UPC || p.up_cin % 32)) || (CH != 0) != (nx != nullptr)) return hipErrorInvalidValue;
   if (CIN && (p.Cin != CIN || (UPC && p.up_cin != up_skip_width<UPC>()))) return hipErrorInvalidValue;
-  constexpr int BMO = BM - 2 - 2 * TIGHT;
+  constexpr int BMO = TIGHT == 2 ? BM : BM - 2 - 2 * TIGHT;
   const int tiles = (p.L + BMO - 1) / BMO;
   hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
   return hipGetLastError();
@@ -70,6 +70,7 @@ hipError_t convblock_init() {
   A(bf16_t, 64, 128, 8, 1, 192, 0, 192); A(bf16_t, 128, 128, 8, 1, 192, 0, 192); A(bf16_t, 64, 192, 8, 1, 256, 0, 256);
   A(bf16_t, 64, 256, 8, 1, 384, 0, 384); A(bf16_t, 48, 256, 8, 1, 384, 0, 384);
   A(bf16_t, 128, 128, 8, 1, 192, 0, 192, 1); A(bf16_t, 48, 256, 8, 1, 384, 0, 384, 1);   // ... writing BM - 4 rows per tile (convblock_core.h, TIGHT)
+  A(bf16_t, 32, 256, 8, 1, 0, 0, 192, 2); A(bf16_t, 32, 256, 8, 1, 384, 0, 384, 2);       // 32-row tiles of the widest blocks, conv1 over 48 rows (TIGHT = 2)
   // encoder blocks that continue into the next EncoderLayer's first half
   A(bf16_t, 64, 192, 8, 1, 0, 1, 128); A(bf16_t, 48, 256, 8, 1, 0, 1, 192); A(bf16_t, 64, 256, 8, 1, 0, 1, 192);
   A(float, 32, 128, 4); A(float, 32, 192, 4); A(float, 32, 256, 4);
@@ -82,6 +83,15 @@ static bool use_bm48(const ConvBlockParams& p) {
   if (const char* e = getenv("DHW_CONV_BM")) return atoi(e) == 48;
   const long t64 = (long)p.B * ((p.L + 61) / 62), t48 = (long)p.B * ((p.L + 45) / 46);
   return t64 < 256 && t48 <= 256 && t48 > t64;
+}
+
+// 32-row tiles with conv1 over 48 rows (TIGHT = 2) for the widest blocks when they fill the CUs in one round where the 46-row
+// tiling leaves some idle (B = 64 at L / 4 = 122: 256 instead of 192 workgroups); DHW_CONV_ASYM=0 switches it off (A/B)
+static bool use_asym32(const ConvBlockParams& p) {
+  static const bool on = !(getenv("DHW_CONV_ASYM") && atoi(getenv("DHW_CONV_ASYM")) == 0);
+  if (!on || getenv("DHW_CONV_BM")) return false;
+  const long t32 = (long)p.B * ((p.L + 31) / 32), t46 = (long)p.B * ((p.L + 45) / 46);
+  return t32 <= 256 && t32 > t46;
 }
 
 hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t st) {
@@ -101,6 +111,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
     }
     if (p.Cout == 192 && p.Cin == 256 && p.up_cin == 192) return launch_t<bf16_t, 64, 192, 8, 1, 256, 0, 256>(p, st);
     if (p.Cout == 256 && p.Cin == 384 && p.up_cin == 256) {
+      if (use_asym32(p)) return launch_t<bf16_t, 32, 256, 8, 1, 384, 0, 384, 2>(p, st);
       if (use_bm48(p) && tight(48)) return launch_t<bf16_t, 48, 256, 8, 1, 384, 0, 384, 1>(p, st);
       return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 384, 0, 384>(p, st) : launch_t<bf16_t, 64, 256, 8, 1, 384, 0, 384>(p, st);
     }
@@ -122,6 +133,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
           return launch_t<bf16_t, 64, 192, 8, 2, 0, 0, 128>(p, st);
         return sk ? launch_t<bf16_t, 64, 192, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 192, 8>(p, st);
       case 256:   // (30-row tiles = 2.5x the workgroups at the L/4 level measured slower: 34.1 vs 30.8 us; env DHW_CONV_BM=32 to retry)
+        if (sk && use_asym32(p)) return launch_t<bf16_t, 32, 256, 8, 1, 0, 0, 192, 2>(p, st);
         if (use_bm48(p)) return sk ? launch_t<bf16_t, 48, 256, 8, 1, 0, 0, 192>(p, st) : launch_t<bf16_t, 48, 256, 8>(p, st);
         if (getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 32) return launch_t<bf16_t, 32, 256, 8>(p, st);
         return sk ? launch_t<bf16_t, 64, 256, 8, 1, 0, 0, 192>(p, st) : launch_t<bf16_t, 64, 256, 8>(p, st);

@@ -64,14 +64,20 @@ template <int UPC> constexpr int up_skip_width() { return UPC == 384 ? 256 : UPC
 // of which 2 rows are used: 4 tiles for 50 rows at BM = 48, 9 for 130 at BM = 128.  Chosen at launch when the row count of the
 // level needs the same number of tiles either way (L / 4 = 122: 3 tiles of 44 or of 46).  The h1 / h2 / output rows past the
 // BM - 4 valid ones are computed from whatever finite values follow the staged tiles in LDS and are never stored.
+// TIGHT = 2 ("asymmetric"): the workgroup writes ALL BM rows of its tile; only conv1 — which must produce BM + 2 rows of h1 for the
+// 3-tap conv2 — runs over one more 16-row tile (BM + 16 rows, 2 of the extra 16 used), conv2 / fc / conv_skip over exactly BM.
+// For the L / 4 level of the bench shape (122 rows per sample): 4 tiles of 32 rows = 256 workgroups with 2 row tiles in three of
+// the four GEMM stages, instead of 3 tiles of 46 (44) rows = 192 workgroups with 3 row tiles in every stage and 64 idle CUs.
 template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, typename P, typename X>
 DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, char* smem) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr bool SK = CIN != 0;          // static contraction lengths
   constexpr int KT1 = 3 * CIN / 32;      // conv1 / conv_skip k-chunks when SK
   static_assert(UPC == 0 || CIN == 0 || CIN == UPC, "a fused input stage produces the block's own input width");
-  constexpr int BMO = BM - 2 - 2 * TIGHT;   // output rows per workgroup
-  constexpr int RX = BMO + 4;               // staged x rows: sample rows [m0 - 2, m0 + BMO + 2)
+  constexpr bool ASYM = TIGHT == 2;
+  constexpr int BMO = ASYM ? BM : BM - 2 - 2 * TIGHT;   // output rows per workgroup
+  constexpr int RX = BMO + 4;                           // staged x rows: sample rows [m0 - 2, m0 + BMO + 2)
+  constexpr int BM1 = ASYM ? BM + 16 : BM;              // h1 rows conv1 computes (index i <-> sample row m0 - 1 + i; BMO + 2 are needed)
   constexpr int C1 = CO / 2;             // conv1 output channels
   // Wave layouts (row groups x channel groups): stage 1 (conv1, C1 channels) and stages 2,3 (CO channels).
   // Every wave streams its OWN weight fragments from L2, so waves that differ only in their row group fetch the same
@@ -88,9 +94,10 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr bool TALL = NW == 8 && BM >= 128 && T2 == 8;
   constexpr int WN2 = NW == 8 ? (TALL ? 4 : (T2 % 8 == 0 ? 8 : 6)) : 4;
   constexpr int WM2 = TALL ? 2 : 1;
-  constexpr int MT1 = BM / WM1 / 16, NT1 = T1 / WN1;
+  constexpr int MT1 = BM1 / WM1 / 16, NT1 = T1 / WN1;
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
-  static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
+  static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
+  static_assert(!ASYM || (CH == 0 && WM1 == 1), "the asymmetric tiling: plain blocks with one row group in conv1");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
 
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
@@ -100,8 +107,8 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = h2_stride<T, BM>(CO);
   char* XS = smem;                       // SiLU(x)   [RX][Cin]
   char* XR = XS + RX * SX;               // x         [RX][Cin]
-  char* H1 = XR + RX * SX;               // h1        [BM+2][C1]  (index i <-> sample row m0-1+i)
-  char* H2 = H1 + (BM + 2) * SH1;        // h2        [BM][CO]    (index i <-> sample row m0+i)
+  char* H1 = XR + RX * SX;               // h1        [BM1+2][C1]  (index i <-> sample row m0-1+i)
+  char* H2 = H1 + (BM1 + 2) * SH1;       // h2        [BM][CO]    (index i <-> sample row m0+i)
   const float* gam = p.film + (size_t)b * p.film_bs;
   const float* bet = gam + p.film_tot;
 
@@ -110,7 +117,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   // `if (act)` around a stage whose loads are consumed inside it leaves, on the (never taken) skip path, loads that were
   // never waited for, and hipcc's s_waitcnt merge at the join then drains the next stage's weight prefetch (r2, .s).
   const bool act1 = WM1 * WN1 == NW || wave < WM1 * WN1, act2 = WM2 * WN2 == NW || wave < WM2 * WN2;
-  const int wm1 = act1 ? wave / WN1 : 0, wn1 = act1 ? wave % WN1 : 0, row01 = wm1 * (BM / WM1), nt01 = wn1 * NT1;
+  const int wm1 = act1 ? wave / WN1 : 0, wn1 = act1 ? wave % WN1 : 0, row01 = wm1 * (BM1 / WM1), nt01 = wn1 * NT1;
   const int wm2 = act2 ? wave / WN2 : 0, wn2 = act2 ? wave % WN2 : 0, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
@@ -295,7 +302,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
     }
     // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
     for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
-      *reinterpret_cast<uint4*>(H1 + BM * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(H1 + BM1 * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   }
   STAMP(13);
   CB_BARRIER();
@@ -411,17 +418,19 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   STAMP(9);
 }
 
+// (bm1: the h1 rows conv1 computes = BM, or BM + 16 for the asymmetric tiling, whose x tiles are BM + 4 rows)
 template <typename T, int BM, int CO>
-inline size_t lds_bytes(int Cin, int up_cin = 0) {
-  const size_t xt = (size_t)2 * (BM + 2) * tile_stride<T>(Cin);
-  const size_t ops = xt + (size_t)(BM + 2) * tile_stride<T>(CO / 2) + (size_t)BM * h2_stride<T, BM>(CO);
+inline size_t lds_bytes(int Cin, int up_cin = 0, int bm1 = BM) {
+  const int rx = bm1 > BM ? BM + 4 : BM + 2;
+  // (conv1's discarded rows read up to 2 x rows past its last computed row: they must lie inside the allocation)
+  const size_t xt = (size_t)2 * rx * tile_stride<T>(Cin);
+  const size_t ops = xt + (size_t)(bm1 + 2) * tile_stride<T>(CO / 2) + (size_t)BM * h2_stride<T, BM>(CO);
   const size_t outf = (size_t)BM * (CO * 4 + 16);
   // x tiles + staged h rows (with 12 channel tiles the input GEMM runs as 2 row groups of ceil(MTU / 2) tiles: the second
   // group's surplus tile reads rows past the staged ones, which must still lie inside the allocation)
-  const int mtu = (BM + 2 + 15) / 16, wmu = (Cin / 16) % 8 == 0 ? 1 : 2, rows_read = wmu * ((mtu + wmu - 1) / wmu) * 16 + 2;
+  const int mtu = (rx + 15) / 16, wmu = (Cin / 16) % 8 == 0 ? 1 : 2, rows_read = wmu * ((mtu + wmu - 1) / wmu) * 16 + 2;
   const size_t up = up_cin ? xt + (size_t)rows_read * tile_stride<T>(up_cin) : 0;
   return std::max(ops, std::max(outf, up));
 }
-
 
 }  // namespace
