@@ -260,7 +260,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
-    store_tiles<T, NT, MT>(lane, QR, S, row0, n0, acc);
+    enc_store_tiles<T, NT, MT>(lane, QR, S, row0, n0, acc);
     ENC_STAMP(9);
   }
   lds_barrier();
@@ -340,7 +340,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(reinterpret_cast<const T*>(XR + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
-      store_tiles<T, NT, MT>(lane, XR, S, row0, n0, acc);
+      enc_store_tiles<T, NT, MT>(lane, XR, S, row0, n0, acc);
     }
   }
   lds_barrier();
@@ -402,7 +402,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
         for (int i = 0; i < NT; ++i)
 #pragma unroll
           for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
-        store_tiles<T, NT, MT>(lane, QR, S, row0, n0 + opaque, acc);
+        enc_store_tiles<T, NT, MT>(lane, QR, S, row0, n0 + opaque, acc);
       }
       lds_barrier();
       tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);

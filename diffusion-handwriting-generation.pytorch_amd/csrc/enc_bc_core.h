@@ -280,9 +280,9 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i];
-      store_tiles<T, NT, MT>(lane, R2, S, row0, n0, acc);
+      enc_store_tiles<T, NT, MT>(lane, R2, S, row0, n0, acc);
       silu_tiles2<T, NT, MT>(acc);
-      store_tiles<T, NT, MT>(lane, R1, S, row0, n0, acc);
+      enc_store_tiles<T, NT, MT>(lane, R1, S, row0, n0, acc);
     }
   }
   WST(8);
@@ -312,7 +312,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
       silu_tiles2<T, NT, MT>(acc);
-      store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc);
+      enc_store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc);
     }
     WST(12 + 6 * hh);
     lds_barrier();
@@ -351,7 +351,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc2[i][j] = acc2[i][j] * ep.gam[i] + ep.bet[i];
-    store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc2);
+    enc_store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc2);
   }
   lds_barrier();
   const int rows_valid = min(BM, p.Lk - m0);
@@ -403,7 +403,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       for (int i = 0; i < NTN; ++i)
 #pragma unroll
         for (int j = 0; j < MTN; ++j) acc[i][j] += epd.bias[i];
-      store_tiles<T, NTN, MTN>(lane, XN, SN, 0, nn0, acc);
+      enc_store_tiles<T, NTN, MTN>(lane, XN, SN, 0, nn0, acc);
     }
     lds_barrier();
     const int m02 = m0 / 2, rows2 = rows_valid / 2;

@@ -118,6 +118,22 @@ DHW_DEV void store_tiles(int lane, char* tile, int S, int row0, int n0, const f3
   }
   if constexpr (N & 1) store_one<T>(ptr(N - 1), v[NT - 1][MT - 1], keep(MT - 1), valid(MT - 1));
 }
+#ifndef DHW_ENC_PAIRST
+#define DHW_ENC_PAIRST 0   // 1 = paired 16-byte stores (lane exchange) in the EncoderLayer epilogues too: measured 19.08 vs 19.01 ms (profiles/r04_enc_pairstore_ab.log) -> off
+#endif
+// the EncoderLayer kernels' form: paired 16-byte stores, or (DHW_ENC_PAIRST=0) one 8-byte store per tile
+template <typename T, int NT, int MT>
+DHW_DEV void enc_store_tiles(int lane, char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT]) {
+  if constexpr (DHW_ENC_PAIRST) {
+    store_tiles<T, NT, MT>(lane, tile, S, row0, n0, v, [](int) { return true; }, [](int) { return true; });
+  } else {
+    const int l15 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) store4(reinterpret_cast<T*>(tile + (row0 + j * 16 + l15) * S) + n0 + 16 * i, v[i][j]);
+  }
+}
 template <typename T, int NT, int MT>
 DHW_DEV void store_tiles(int lane, char* tile, int S, int row0, int n0, const f32x4 (&v)[NT][MT]) {
   store_tiles<T, NT, MT>(lane, tile, S, row0, n0, v, [](int) { return true; }, [](int) { return true; });
