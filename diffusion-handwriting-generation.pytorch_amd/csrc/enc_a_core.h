@@ -175,6 +175,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #ifndef DHW_ENC_XSTREAM
 #define DHW_ENC_XSTREAM 0   // measured: 19.05 vs 18.98 ms per 60-step batch (profiles/r04_xstream_ab.log) -> off
 #endif
+#ifndef DHW_ENC_EARLYFILL
+#define DHW_ENC_EARLYFILL 0   // measured 19.13 vs 19.08 ms (profiles/r04_earlyfill_ab.log): the prefetch queues in front of the K / V block the attention waits for
+#endif
+  constexpr bool EARLYA = sizeof(T) == 2 && DHW_ENC_EARLYFILL;
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream with whole-stage rings (gemm_core.h, run_x)
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream: a whole stage at d = 192 / 256, 8 of 12 chunks at d = 384
 #ifndef DHW_RINGA384
@@ -262,6 +266,9 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
     enc_store_tiles<T, NT, MT>(lane, QR, S, row0, n0, acc);
     ENC_STAMP(9);
+    // the dense stage's first weight fragments: requested in front of the cross attention (the vector-memory path is idle during
+    // it), not behind it — see enc_bc_core.h, DHW_ENC_EARLYFILL
+    if constexpr (EARLYA) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);
   }
   lds_barrier();
   ENC_STAMP(2);
@@ -309,7 +316,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     }
   }
   if (act) {
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);   // in flight across the barrier
+    if constexpr (!EARLYA) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);   // in flight across the barrier
     if constexpr (!PLDS) ep.load(p.b_d1, gam + p.f1, bet + p.f1, n0);
   }
   lds_barrier();

@@ -12,6 +12,9 @@ namespace {
 #ifndef DHW_RING384
 #define DHW_RING384 24   // weight fragments in flight per wave in enc_bc's d = 384 stages on 16-row tiles (15 in round 3; 30 / 36 = a whole stage: experiments)
 #endif
+#ifndef DHW_ENC_EARLYFILL
+#define DHW_ENC_EARLYFILL 0   // measured 19.13 vs 19.08 ms (profiles/r04_earlyfill_ab.log): the prefetch queues in front of the K / V block the attention waits for
+#endif
 #ifndef DHW_ENC_XSTREAM
 #define DHW_ENC_XSTREAM 0   // measured: 19.05 vs 18.98 ms per 60-step batch (profiles/r04_xstream_ab.log) -> off
 #endif
@@ -121,6 +124,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   static_assert(!XS || RingT::template next_rot<KC, ROT2>() == ROT1, "FFN loop rotation");
   EpiParams<NT> ep;
   constexpr bool PLDS = enc_plds<T>(), PLFIX = bc_params_fixed<T, DM, BM>();
+  constexpr bool EARLY = sizeof(T) == 2 && DHW_ENC_EARLYFILL;   // the post-attention stage's weight prefetch issued in front of the attention
   float* PL = reinterpret_cast<float*>(smem + lds_bc_tiles<T, DM, BM>());   // (PLFIX; else chosen behind the attention loop)
   ParamStage<8> cp;
   // (a macro, not a lambda: with `cp` captured by a closure hipcc kept it in scratch memory)
@@ -181,6 +185,11 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     }
     if constexpr (PLDS) BC_PARAMS_REQUEST();   // (!PLFIX: held in registers across the key blocks, 8 VGPRs)
     request(0);   // (one round trip together with the q fragments)
+    // The dense stage's first weight fragments are requested HERE, behind the first K / V block, not behind the attention: the
+    // wave waits for that block anyway, the vector-memory path is idle during the attention's LDS / MFMA work, and the stage
+    // then starts on a full ring instead of paying the request burst between the attention and its barrier (per-wave
+    // timelines: 1.6-2.3 kcycles from "att.end" to the barrier, profiles/r04_encbc_wave_timeline_*.log).  DHW_ENC_EARLYFILL=0: as before.
+    if constexpr (EARLY) { if (act) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane); }
     if constexpr (PLDS && PLFIX) cp.template store<DM>(PL, tid);
     commit(0, R2, R2 + KBS * SK);
     lds_barrier();
@@ -232,7 +241,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     cp.template store<DM>(PL, tid);
   }
   if (act) {
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
+    if (!EARLY || (p.dbg & 1)) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
     if constexpr (!PLDS) ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
   }
   WST(2);
