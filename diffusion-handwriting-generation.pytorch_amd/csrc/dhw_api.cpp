@@ -151,7 +151,11 @@ struct EncLayerW {
 }  // namespace
 
 struct dhw_handle {
-  dhw_dims dims{};
+  dhw_dims dims{};      // PHYSICAL dims: what the kernels, workspaces and packed weights are sized for (c2 = 192)
+  dhw_dims ldims{};     // the caller's dims (the reference's constructor arguments): c2 may be any multiple of 12 up to 192
+  bool padded = false;  // ldims.c2 < dims.c2: weights are embedded into the physical shapes with zero padding (pad_weights)
+  std::vector<KeySpec> pspec;                  // physical shapes, same key order as spec
+  std::vector<std::vector<float>> phys_w;      // padded copies of host_w (padded handles only)
   int device = 0;
   int prec = 0;
   size_t es = 2;
@@ -268,7 +272,7 @@ int dev_alloc(dhw_handle* h, void** p, size_t bytes, bool zero = true) {
   return 0;
 }
 
-const std::vector<float>& W(dhw_handle* h, const std::string& key) { return h->host_w[h->key_index.at(key)]; }
+const std::vector<float>& W(dhw_handle* h, const std::string& key) { return (h->padded ? h->phys_w : h->host_w)[h->key_index.at(key)]; }
 
 int upload_f32(dhw_handle* h, const std::vector<float>& v, float** out) {
   int rc = dev_alloc(h, (void**)out, v.size() * 4, false);
@@ -315,8 +319,11 @@ std::vector<float> vcat(std::initializer_list<const std::vector<float>*> vs) {
 }
 
 // Sinusoidal table PE[pos][dim] exactly as attention.py:15-23 evaluates it in fp32.
-std::vector<float> pe_table(int n, int dim, float pos_factor) {
-  const int half = dim / 2;
+// (dim_true < dim: the model's width is below the kernels' physical one; the table keeps the row stride dim, the values of the
+// dim_true-wide encoding sit in columns [0, dim_true) and the rest is zero — the tail padding of pad_weights)
+std::vector<float> pe_table(int n, int dim, float pos_factor, int dim_true = 0) {
+  if (dim_true <= 0) dim_true = dim;
+  const int half = dim_true / 2;
   const float negc = (float)(-(std::log(10000.0) / (half - 1)));
   std::vector<float> pe((size_t)n * dim);
   for (int j = 0; j < half; ++j) {
@@ -341,6 +348,76 @@ std::vector<float> pe_times_w(const std::vector<float>& pe, int n, int dim, cons
       r[(size_t)t * N + o] = (float)a;
     }
   return r;
+}
+
+// ---------------------------------------------------------------- model widths below the kernels' (c2 < 192)
+// The reference's constructor takes any c2 divisible by 12 (model.py:64-71: 3 heads at c2, 6 at 2*c2, 8 in the TextStyleEncoder,
+// text_style.py:78).  The kernels are built for c2 = 192: head dims 64 and 48, LayerNorm widths 192 / 384.  A smaller model is
+// EMBEDDED into those shapes: every c2-derived channel axis is zero padded at the tail (c2/2 -> 96, c2 -> 192, 2*c2 -> 384,
+// 4*c2 -> 768) and the q / k / v projections' output axis (= the attention dense's input axis) head by head (head h's c2/3 or
+// c2/4 channels at the front of its 64- or 48-wide slot).  With zero weights, biases and FiLM rows in the padding every padded
+// channel stays exactly 0 through convolutions, SiLU, residuals, pooling and attention; what is left to handle is (1) LayerNorm:
+// statistics over the true width, padding written as 0 (GemmParams::ln_n, embed_ln's n_true), (2) the attention's 1/sqrt(depth):
+// the kernels scale by the physical head dim, so wq / its bias (and with them PE·Wq) carry sqrt(physical / true), (3) the
+// positional encodings, evaluated for the true width (pe_table).  Such a handle runs the one-launch-per-GEMM path (fuse = false):
+// the fused block kernels keep their compile-time LayerNorm widths.
+int true_width(const dhw_handle* h, int n) {
+  if (!h->padded) return n;
+  const int c2 = h->ldims.c2;
+  switch (n) {
+    case 96: return c2 / 2;
+    case 192: return c2;
+    case 384: return 2 * c2;
+    case 768: return 4 * c2;
+    default: return n;   // c1 = 128 and c3 = 256 are fixed, so 32 / 64 / 128 / 256 / 512 are never c2-derived
+  }
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int pad_weights(dhw_handle* h) {
+  h->phys_w.assign(h->spec.size(), {});
+  for (size_t i = 0; i < h->spec.size(); ++i) {
+    const KeySpec& lk = h->spec[i];
+    const KeySpec& pk = h->pspec[i];
+    const std::string& key = lk.key;
+    if (lk.shape.size() != pk.shape.size() || lk.shape.size() > 3) return fail(h, DHW_ERR_ARG, "pad: rank of %s", key.c_str());
+    // heads of the attention module this tensor belongs to (0 = not a q/k/v/dense tensor of an attention)
+    int heads = 0;
+    if (key.find(".mha") != std::string::npos)
+      heads = key.compare(0, 4, "enc3") == 0 ? 3 : key.compare(0, 4, "enc5") == 0 ? 4 : key.compare(0, 10, "att_layers") == 0 ? 6 : 8;
+    const bool is_dense = key.find(".dense.") != std::string::npos;
+    const bool is_q = key.find(".wq.") != std::string::npos;
+    int head_axis = -1;   // axis laid out head by head
+    if (heads) head_axis = is_dense ? (ends_with(key, ".weight") ? 1 : -1) : 0;
+    int64_t ls[3] = {1, 1, 1}, ps[3] = {1, 1, 1};
+    for (size_t a = 0; a < lk.shape.size(); ++a) { ls[a] = lk.shape[a]; ps[a] = pk.shape[a]; }
+    std::vector<int64_t> map[3];
+    float qscale = 1.0f;
+    for (int a = 0; a < 3; ++a) {
+      map[a].resize(ls[a]);
+      if (a == head_axis && ls[a] != ps[a]) {
+        const int64_t dl = ls[a] / heads, dp = ps[a] / heads;
+        if (dl * heads != ls[a] || dp * heads != ps[a] || dl > dp) return fail(h, DHW_ERR_ARG, "pad: head split of %s", key.c_str());
+        for (int64_t j = 0; j < ls[a]; ++j) map[a][j] = (j / dl) * dp + j % dl;
+        if (is_q) qscale = std::sqrt((float)dp / (float)dl);
+      } else {
+        if (ls[a] > ps[a]) return fail(h, DHW_ERR_ARG, "pad: %s is wider than its physical shape", key.c_str());
+        for (int64_t j = 0; j < ls[a]; ++j) map[a][j] = j;
+      }
+    }
+    const std::vector<float>& src = h->host_w[i];
+    std::vector<float>& dst = h->phys_w[i];
+    dst.assign((size_t)(ps[0] * ps[1] * ps[2]), 0.f);
+    size_t o = 0;
+    for (int64_t x = 0; x < ls[0]; ++x)
+      for (int64_t y = 0; y < ls[1]; ++y)
+        for (int64_t z = 0; z < ls[2]; ++z) dst[(size_t)((map[0][x] * ps[1] + map[1][y]) * ps[2] + map[2][z])] = src[o++] * qscale;
+  }
+  return 0;
 }
 
 int pack_convblock(dhw_handle* h, const std::string& n, int cin, int cout, ConvBlockW& cb) {
@@ -390,8 +467,8 @@ int pack_enclayer(dhw_handle* h, const std::string& n, int d, int heads, float p
   if ((rc = upload_f32(h, W(h, n + ".ffn.1.bias"), &e.b_f1))) return rc;
   if ((rc = upload_f32(h, W(h, n + ".ffn.3.bias"), &e.b_f2))) return rc;
   // (x + PE)·W = x·W + PE·W: the PE term is a per-position bias table (model.py:40-50, attention.py:15-23)
-  const auto pe_t = pe_table(h->dims.max_Lt + SLACK_ROWS, d, 1.0f);                 // text_pe_gen: pos_factor 1 (model.py:22)
-  const auto pe_x = pe_table(max_lk + SLACK_ROWS, d, pf);                           // stroke_pe_gen
+  const auto pe_t = pe_table(h->dims.max_Lt + SLACK_ROWS, d, 1.0f, true_width(h, d));   // text_pe_gen: pos_factor 1 (model.py:22)
+  const auto pe_x = pe_table(max_lk + SLACK_ROWS, d, pf, true_width(h, d));             // stroke_pe_gen
   if ((rc = upload_f32(h, pe_times_w(pe_t, h->dims.max_Lt + SLACK_ROWS, d, wk1, d), &e.pb_k1))) return rc;
   if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, wq1, d), &e.pb_q1))) return rc;
   if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, vcat({&wq2, &wk2}), 2 * d), &e.pb_qk2))) return rc;
@@ -504,7 +581,7 @@ int alloc_shared(dhw_handle* h) {
 
 void build_film_layout(dhw_handle* h) {
   int off = 0;
-  for (const KeySpec& k : h->spec) {
+  for (const KeySpec& k : h->pspec) {
     const std::string suf = ".gamma_emb.weight";
     if (k.key.size() > suf.size() && k.key.compare(k.key.size() - suf.size(), suf.size(), suf) == 0) {
       h->film_off[k.key.substr(0, k.key.size() - suf.size())] = off;
@@ -623,7 +700,9 @@ void run_gemm(Ctx& c, const char* label, const GemmParams& p) {
   if (c.rec) { c.rec_fail = true; return; }
   if (c.err) return;
   Launch l(c.h, c.st, label, gemm_flops(p), gemm_bytes(c.h, p));
-  hipError_t e = launch_gemm(c.h->prec, p, c.st);
+  GemmParams q = p;
+  if (q.ln) q.ln_n = true_width(c.h, q.N);
+  hipError_t e = launch_gemm(c.h->prec, q, c.st);
   if (e != hipSuccess) c.err = fail(c.h, DHW_ERR_HIP, "gemm %s: %s", label, hipGetErrorString(e));
 }
 void run_attn(Ctx& c, const char* label, const AttnParams& p) {
@@ -964,7 +1043,7 @@ void text_style_static(Ctx& c, const int64_t* text, const float* style) {
     p.out = BUF(c, "sty_n");
     run_gemm(c, "style.ffn2_ln", p);
   }
-  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, VOCAB, BUF(c, "t_n"), c.st));
+  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, true_width(h, dt), VOCAB, BUF(c, "t_n"), c.st));
 }
 
 // sigma-dependent part of TextStyleEncoder (text_style.py:94-104) + the per-layer text projections
@@ -1226,7 +1305,8 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   *out = nullptr;
   const dhw_dims& d = *dims;
   if (d.c1 != 128 || d.c3 != 256) return fail(nullptr, DHW_ERR_ARG, "c1 must be 128 and c3 256 (reference conditioning.py:9-10, model.py:103)");
-  if (d.c2 != 192) return fail(nullptr, DHW_ERR_ARG, "c2 must be 192: the attention kernels are built for head dims 64 (c2/3, c3/4, 2*c2/6) and 48 (2*c2/8)");
+  if (d.c2 < 12 || d.c2 > 192 || d.c2 % 12)
+    return fail(nullptr, DHW_ERR_ARG, "c2 must be a multiple of 12 (model.py:88-106: 3 / 6 / 8 attention heads) and at most 192, the width the kernels are built for");
   if (d.num_layers < 0 || d.num_layers > 16 || d.max_B < 1 || d.max_L < 8 || d.max_L % 8 || d.max_Lt < 1 || d.S < 1 || (d.S * 1280) % STYLE_CH)
     return fail(nullptr, DHW_ERR_ARG, "dhw_create: bad dims");
   if (d.precision != DHW_PREC_BF16 && d.precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "bad precision");
@@ -1234,11 +1314,15 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, DHW_ERR_HIP, "no HIP device available");
   if (device < 0 || device >= ndev) return fail(nullptr, DHW_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
   dhw_handle* h = new dhw_handle();
+  h->ldims = d;
   h->dims = d;
+  h->dims.c2 = 192;
+  h->padded = d.c2 != 192;
   h->device = device;
   h->prec = d.precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
   h->es = h->prec == PREC_F32 ? 4 : 2;
   h->spec = build_spec(d.num_layers, d.c1, d.c2, d.c3);
+  h->pspec = build_spec(d.num_layers, d.c1, h->dims.c2, d.c3);
   for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
   h->host_w.resize(h->spec.size());
   h->loaded.assign(h->spec.size(), 0);
@@ -1264,6 +1348,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
   if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
   if (const char* e = getenv("DHW_PERSIST")) h->persist = atoi(e) != 0;
+  if (h->padded) h->fuse = false;   // (pad_weights: the fused block kernels have compile-time LayerNorm widths)
   if (!rc && h->prec == PREC_BF16 && h->persist) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || persist_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "persistent kernel setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1343,6 +1428,7 @@ int dhw_finalize(dhw_handle* h) {
   const dhw_dims& d = h->dims;
   const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
   int rc;
+  if (h->padded && (rc = pad_weights(h))) return rc;
   // (re-packing leaks the previous packed copies until destroy; weights are loaded once in practice)
   {  // FiLM: all gamma/beta projections concatenated -> [2*TOT, 32]
     std::vector<float> w((size_t)2 * h->film_tot * SIG), b((size_t)2 * h->film_tot);
@@ -1722,7 +1808,7 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
 
 int dhw_work(dhw_handle* h, int L, int Lt, double* flops_out, double* bytes_out) {
   if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  const dhw_dims& d = h->dims;
+  const dhw_dims& d = h->ldims;   // the model's own widths: zero padding (pad_weights) is not algorithmic work
   const double c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2, S5 = d.S * 5;
   auto cb = [](double L_, double ci, double co) { return 2 * L_ * (3 * ci * co + 1.5 * ci * co + 1.5 * co * co + co * co); };
   auto el = [&](double Lk, double dm, double heads) {

@@ -35,6 +35,9 @@ struct GemmParams {
   const void* res2;      // added after FiLM: [B*L, N], or [B*L/2, N] when res2_half (nearest x2 upsample)
   int res2_half;
   int ln;                // LayerNorm over the N channels (eps 1e-6, no affine); needs BN == N
+  int ln_n;              // channels the statistics run over: columns [ln_n, N) are zero padding (model widths below the kernels'
+                         // physical ones, dhw_api.cpp pad_weights) and are written as 0; 0 = N
+  float ln_inv;          // 1 / ln_n (filled in by launch_gemm)
   int silu_out;
   int relu6_out;         // clamp to [0, 6] (MobileNetV2 pointwise convolutions of the StyleExtractor, style.hip)
   void* out;             // [B*L, n_store] element type, or fp32 when out_f32
@@ -150,7 +153,8 @@ hipError_t launch_sigma_ffn(const float* sigma, int n, const float* w1, const fl
 hipError_t launch_film(const float* sig32, int n, const float* wcat, const float* bcat, int cols,
                        float* film, hipStream_t st);
 // t_n = LN(emb[text])  (text_style.py:96-97), element type out
-hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int vocab,
+// (n_true: channels the statistics run over; the table's columns [n_true, dim) are zero padding and stay 0)
+hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int n_true, int vocab,
                            void* out, hipStream_t st);
 // out[b, r, c] = in[b % in_B, r, c] * gam[(b / div)*bs + c] + bet[(b / div)*bs + c]
 hipError_t launch_film_apply(int prec, const void* in, int in_B, int B, int rows, int dim, const float* gam,

@@ -211,15 +211,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WN; ++w) s += red[w * BM + row0 + j * 16 + l15];
-      mean[j] = s * (1.0f / BN);
+      mean[j] = s * p.ln_inv;
     }
+    const bool padded = p.ln_n < BN;   // (uniform) statistics over the first ln_n channels; the rest is zero padding
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; s += d * d; }
+        for (int r = 0; r < 4; ++r) {
+          float d = acc[i][j][r] - mean[j];
+          if (padded && wn * (BN / WN) + i * 16 + 4 * g + r >= p.ln_n) d = 0.f;
+          s += d * d;
+        }
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       if (g == 0) red[(WN + wn) * BM + row0 + j * 16 + l15] = s;
@@ -230,12 +235,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WN; ++w) s += red[(WN + w) * BM + row0 + j * 16 + l15];
-      rstd[j] = rsqrtf(s * (1.0f / BN) + 1e-6f);
+      rstd[j] = rsqrtf(s * p.ln_inv + 1e-6f);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = (acc[i][j] - mean[j]) * rstd[j];
+    if (padded) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (wn * (BN / WN) + i * 16 + 4 * g + r >= p.ln_n) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j][r] = 0.f;
+          }
+    }
   }
 
   // ---- final epilogue -> output tile in LDS -> whole coalesced rows to global (per-lane 8-byte stores straight from
@@ -404,7 +419,12 @@ void gemm_tile_for(int prec, const GemmParams& p, int* BM, int* BN) {
   *BN = bn;
 }
 
-hipError_t launch_gemm(int prec, const GemmParams& p, hipStream_t st) {
+hipError_t launch_gemm(int prec, const GemmParams& p_in, hipStream_t st) {
+  GemmParams p = p_in;
+  if (p.ln) {
+    if (p.ln_n <= 0 || p.ln_n > p.N) p.ln_n = p.N;
+    p.ln_inv = 1.0f / (float)p.ln_n;
+  }
   if (p.film_div < 1 || p.nseg < 1 || p.nseg > 2 || p.N % 16 || p.n_store % 16 || (p.pool && (p.L & 1))) return hipErrorInvalidValue;
   for (int s = 0; s < p.nseg; ++s)
     if (p.seg[s].C % 32 || (p.seg[s].taps != 1 && p.seg[s].taps != 3)) return hipErrorInvalidValue;

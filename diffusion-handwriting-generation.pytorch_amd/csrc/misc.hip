@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void film_kernel(const float* sig32, const flo
 
 // ---- LN(emb[text]) (text_style.py:96-97): one wave per token
 template <typename T>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* text, int rows, const float* emb, int dim,
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* text, int rows, const float* emb, int dim, int n_true,
                                                         int vocab, T* out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -53,14 +53,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* text, int 
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const float* e = emb + id * dim;
   float s = 0.f;
-  for (int c = lane; c < dim; c += 64) s += e[c];
+  for (int c = lane; c < n_true; c += 64) s += e[c];
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / dim;
+  const float mean = s / n_true;
   float v = 0.f;
-  for (int c = lane; c < dim; c += 64) { const float d = e[c] - mean; v += d * d; }
+  for (int c = lane; c < n_true; c += 64) { const float d = e[c] - mean; v += d * d; }
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  const float rstd = rsqrtf(v / dim + 1e-6f);
-  for (int c = lane; c < dim; c += 64) out[(size_t)row * dim + c] = from_f<T>((e[c] - mean) * rstd);
+  const float rstd = rsqrtf(v / n_true + 1e-6f);
+  for (int c = lane; c < dim; c += 64) out[(size_t)row * dim + c] = from_f<T>(c < n_true ? (e[c] - mean) * rstd : 0.f);
 }
 
 template <typename T>
@@ -157,12 +157,12 @@ hipError_t launch_film(const float* sig32, int n, const float* wcat, const float
   hipLaunchKernelGGL(film_kernel, dim3(nblk(cols, 256), n), dim3(256), 0, st, sig32, wcat, bcat, cols, film);
   return hipGetLastError();
 }
-hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int vocab, void* out,
+hipError_t launch_embed_ln(int prec, const int64_t* text, int rows, const float* emb, int dim, int n_true, int vocab, void* out,
                            hipStream_t st) {
   if (prec == PREC_BF16)
-    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, vocab, (bf16_t*)out);
+    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, n_true, vocab, (bf16_t*)out);
   else
-    hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, vocab, (float*)out);
+    hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, st, text, rows, emb, dim, n_true, vocab, (float*)out);
   return hipGetLastError();
 }
 hipError_t launch_film_apply(int prec, const void* in, int in_B, int B, int rows, int dim, const float* gam,

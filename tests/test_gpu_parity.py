@@ -77,6 +77,40 @@ def test_forward_matches_reference_golden(golden_dir, prec, fname, nl):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("c2", [48, 96, 24])
+def test_other_model_widths_match_reference_golden(golden_dir, prec, c2):
+    """The reference's constructor takes any c2 divisible by 12 (model.py:64-71; SURVEY's tiny case c = (128, 48, 256)): such a
+    model is embedded into the c2 = 192 kernels with zero-padded channels (dhw_api.cpp pad_weights).  Fixtures: the real reference
+    at that width (oracle/make_golden_c2.py): single forwards at three schedule points and per-row sigma, and a 6-step reverse loop."""
+    g = np.load(os.path.join(golden_dir, f"fwd_c2_{c2}.npz"))
+    B, L, Lt, T = int(g["B"]), int(g["L"]), int(g["Lt"]), int(g["T"])
+    m = dhg_amd.DiffusionModel(2, 128, c2, 256, precision=prec, max_B=B, max_L=L, max_Lt=Lt).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(2, 128, c2, 256).items()}, strict=True)
+    inp = spec.synthetic_inputs(B, L, Lt, seed=int(g["seed"]), pad=int(g["pad"]), T=T)
+    alpha = dhg_amd.get_alpha_set()
+    tol = TOL[prec]
+    for i in (59, 30, 0):
+        eps, pen = fwd(m, inp, torch.sqrt(alpha[i]) * torch.ones((B, 1, 1)))
+        assert np.abs(eps - g[f"eps_i{i}"]).max() < tol["eps"], i
+        assert np.abs(pen - g[f"pen_i{i}"]).max() < tol["pen"], i
+    eps, pen = fwd(m, inp, torch.from_numpy(g["sigma_rand"]))
+    assert np.abs(eps - g["eps_rand"]).max() < tol["eps"]
+    assert np.abs(pen - g["pen_rand"]).max() < tol["pen"]
+    out = dhg_amd.sample(m, torch.from_numpy(inp["text"]).cuda(), torch.from_numpy(inp["style"]).cuda(), L=L, T=T,
+                         noise=torch.from_numpy(inp["noise"]).cuda()).cpu().numpy()
+    ref = g["loop_out"]
+    xmax = np.abs(ref[..., :2]).max()
+    assert np.abs(out[..., :2] - ref[..., :2]).max() < (1e-3 if prec == "fp32" else 0.02 * xmax)
+    assert np.abs(out[..., 2] - ref[..., 2]).max() < (1e-4 if prec == "fp32" else 2e-2)
+    # the oracle at the same width agrees too (it restates the reference for any constructor arguments)
+    sd = {k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(2, 128, c2, 256).items()}
+    sg = torch.from_numpy(g["sigma_rand"])
+    with torch.no_grad():
+        e_o, p_o = ref_cpu.forward(sd, torch.from_numpy(inp["strokes"]), torch.from_numpy(inp["text"]), sg, torch.from_numpy(inp["style"]))
+    assert np.abs(e_o.numpy() - g["eps_rand"]).max() < 2e-5 and np.abs(p_o.numpy() - g["pen_rand"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_every_block_matches_reference_taps(golden_dir, prec):
     g = np.load(os.path.join(golden_dir, "taps.npz"))
     B, L, Lt = int(g["B"]), int(g["L"]), int(g["Lt"])

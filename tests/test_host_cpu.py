@@ -146,7 +146,7 @@ def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
 def test_create_rejects_bad_dims():
     l = _lib.lib()
     h = C.c_void_p()
-    for bad in (dict(c1=64), dict(c3=128), dict(c2=96), dict(max_L=10), dict(precision=7), dict(S=0)):
+    for bad in (dict(c1=64), dict(c3=128), dict(c2=100), dict(c2=204), dict(c2=0), dict(max_L=10), dict(precision=7), dict(S=0)):
         kw = dict(num_layers=2, c1=128, c2=192, c3=256, max_B=1, max_L=8, max_Lt=1, S=14, precision=0)
         kw.update(bad)
         assert l.dhw_create(C.byref(h), C.byref(_lib.DhwDims(**kw)), 0) == -1, bad

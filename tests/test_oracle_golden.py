@@ -57,6 +57,25 @@ def test_forward_matches_reference(golden_dir, fname, nl):
         assert np.abs(pen.numpy() - g["pen_rand"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("c2", [48, 96, 24])
+def test_forward_matches_reference_at_other_widths(golden_dir, c2):
+    """model.py:64-71 takes any c2 divisible by 12; fixtures from the real reference at that width (oracle/make_golden_c2.py)."""
+    g = np.load(os.path.join(golden_dir, f"fwd_c2_{c2}.npz"))
+    sd = {k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(2, 128, c2, 256).items()}
+    B, L, Lt, T = int(g["B"]), int(g["L"]), int(g["Lt"]), int(g["T"])
+    inp = spec.synthetic_inputs(B, L, Lt, seed=int(g["seed"]), pad=int(g["pad"]), T=T)
+    x, text, style = (torch.from_numpy(inp[k]) for k in ("strokes", "text", "style"))
+    alpha = ref_cpu.get_alpha_set(ref_cpu.get_beta_set())
+    with torch.no_grad():
+        for i in (59, 30, 0):
+            eps, pen = ref_cpu.forward(sd, x, text, torch.sqrt(alpha[i]) * torch.ones((B, 1, 1)), style)
+            assert np.abs(eps.numpy() - g[f"eps_i{i}"]).max() < 1e-5
+            assert np.abs(pen.numpy() - g[f"pen_i{i}"]).max() < 1e-5
+        out = ref_cpu.sample(sd, text, style, L, torch.from_numpy(inp["noise"]), T=T, mode="new")
+    out = out[0] if isinstance(out, tuple) else out
+    assert np.abs(out.numpy() - g["loop_out"]).max() < 1e-4
+
+
 def test_block_taps_match_reference(golden_dir, sd2):
     g = np.load(os.path.join(golden_dir, "taps.npz"))
     B, L, Lt = int(g["B"]), int(g["L"]), int(g["Lt"])
