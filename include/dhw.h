@@ -54,7 +54,8 @@ enum { DHW_PREC_BF16 = 0,  /* bf16 activations + weights, fp32 accumulate/LN/sof
 
 typedef struct {
   int num_layers;   /* bottleneck EncoderLayers (model.py:66; shipped configs use 2) */
-  int c1, c2, c3;   /* 128 / 192 / 256 (model.py:67-69); c1 must be 128 and c3 256 */
+  int c1, c2, c3;   /* 128 / 192 / 256 (model.py:67-69); c1 must be 128 and c3 256; c2 any multiple of 12 up to 192
+                       (3 / 6 / 8 attention heads, model.py:88-106): widths below 192 run zero-padded inside the 192-wide kernels */
   int max_B;        /* largest batch a call may pass */
   int max_L;        /* largest stroke length (multiple of 8, model.py:169-175) */
   int max_Lt;       /* largest token count */
