@@ -53,6 +53,31 @@ def check_token_ids(text: torch.Tensor, seen: list | None = None) -> None:
         del seen[:-4]
 
 
+class _DifferentiableForward(torch.autograd.Function):
+    """``DiffusionModel.forward`` under autograd (reference train.py:46-60: ``model(x, text, sigma, style)`` ... ``loss.backward()``):
+    the forward and backward passes of ``train_model.TrainModel`` (hand-written fp32 HIP ops, include/dhw_train.h) as ONE autograd
+    node whose inputs are the model's parameters.  The tape lives in the TrainModel, so a backward belongs to the model's LATEST
+    differentiable forward (what a training loop does); an older graph raises instead of returning another batch's gradients."""
+
+    @staticmethod
+    def forward(ctx, model, strokes, text, sigma, style, *params):
+        tm = model._trainer
+        score, pen = tm.forward(strokes, text.to("cpu"), sigma.reshape(strokes.shape[0], 1), style)
+        model._train_generation += 1
+        ctx.model, ctx.generation = model, model._train_generation
+        return score.clone(), pen.clone()
+
+    @staticmethod
+    def backward(ctx, d_score, d_pen):
+        model = ctx.model
+        tm = model._trainer
+        if tm is None or tm.tape is None or ctx.generation != model._train_generation:
+            raise RuntimeError("DiffusionModel: backward through a forward that is not the model's latest one (one graph at a time)")
+        tm.zero_grad()
+        tm.backward(d_score.to(tm.dev, torch.float32), d_pen.to(tm.dev, torch.float32))
+        return (None, None, None, None, None) + tuple(tm.p[k].g.clone() for k in tm.names)
+
+
 def _torch_dtype_code(t: torch.Tensor) -> int:
     return {torch.float32: _lib.DHW_F32, torch.bfloat16: _lib.DHW_BF16, torch.float16: _lib.DHW_F16,
             torch.float64: _lib.DHW_F64}[t.dtype]
@@ -73,6 +98,8 @@ class DiffusionModel(nn.Module):
         self._handle = None
         self._handle_dev = None
         self._wtoken = None
+        self._trainer = None          # train_model.TrainModel behind the differentiable forward (created on first use)
+        self._train_generation = 0
         for name, shape, kind in param_spec(num_layers, c1, c2, c3):
             node = self
             parts = name.split(".")
@@ -145,10 +172,53 @@ class DiffusionModel(nn.Module):
                        self._handle)
         _lib.check(l.dhw_finalize(self._handle), self._handle)
 
+    # ------------------------------------------------------------------ training: the same object under autograd
+    def train(self, mode: bool = True):
+        """``model.train()`` also marks the parameters as requiring gradients, the state a freshly constructed reference model is
+        in (train.py:26-45 goes straight from the constructor to the optimizer); the constructor itself leaves them frozen so that
+        plain inference calls never record a graph."""
+        super().train(mode)
+        if mode:
+            self.requires_grad_(True)
+        return self
+
+    def _link_trainer(self, dev: torch.device):
+        """Make every parameter a VIEW of the TrainModel's flat fp32 buffer (Conv1d weights: the permuted view of its
+        [tap][Cout][Cin] storage), so an optimizer's in-place updates are the training kernels' weights without a copy, and
+        re-link after anything that re-allocated the parameters (``.to()``, ``.cuda()``)."""
+        from . import train_model as tm_mod
+        tm = self._trainer
+        if tm is None or tm.dev != dev:
+            tm = self._trainer = tm_mod.TrainModel({k: v.detach() for k, v in self.state_dict().items()}, self.num_layers, device=dev,
+                                                   drop_rate=0.0, precision="fp32")
+        for k, p in self.named_parameters():
+            view = tm.p[k].d
+            if p.data_ptr() != view.data_ptr() or p.device != view.device:
+                view.copy_(p.detach().to(dev, torch.float32))
+                p.data = view
+        tm.drop_rate = float(self.drop_rate) if self.training else 0.0      # EncoderLayer dropout (model.py:23)
+        tm.style_drop = tm.STYLE_DROP if self.training else 0.0             # TextStyleEncoder's Dropout(0.3) (text_style.py:88)
+        return tm
+
     # ------------------------------------------------------------------ forward == reference model.py:121-182
     def forward(self, strokes: torch.Tensor, text: torch.Tensor, sigma: torch.Tensor, style_vector: torch.Tensor):
         """strokes [B,T,2], text int [B,Lt] (0 = pad), sigma [B,1] or [B,1,1], style_vector [B,S,1280]
-        -> (eps [B,T,2] fp32, pen_lifts [B,T] fp32 in (0,1), None)."""
+        -> (eps [B,T,2] fp32, pen_lifts [B,T] fp32 in (0,1), None).
+
+        With autograd recording and parameters that require gradients (after ``model.train()`` / ``requires_grad_(True)``) the
+        outputs carry a graph back to the parameters: the call runs the fp32 training kernels (``train_model.TrainModel``) with
+        dropout as ``self.training`` says, and ``loss.backward()`` fills ``p.grad`` as the reference's would (train.py:46-60).
+        Gradients with respect to the INPUTS are not produced (the reference's training loop does not use them)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if strokes.dim() != 3 or strokes.shape[-1] != 2 or strokes.shape[1] % 8:
+                raise ValueError("strokes must be [B, T, 2] with T a multiple of 8")
+            check_token_ids(text)
+            dev = self._device(strokes, text, sigma, style_vector)
+            with torch.cuda.device(dev):
+                tm = self._link_trainer(dev)
+                named = dict(self.named_parameters())
+                eps, pen = _DifferentiableForward.apply(self, strokes, text, sigma, style_vector, *(named[k] for k in tm.names))
+            return eps.to(strokes.device), pen.to(strokes.device), None
         if strokes.dim() != 3 or strokes.shape[-1] != 2:
             raise ValueError("strokes must be [B, T, 2]")
         B, L, _ = strokes.shape

@@ -488,6 +488,7 @@ class TrainModel:
             raise ValueError("the FiLM weight rows are not 16-byte aligned in the flat parameter buffer (unexpected state_dict sizes / order)")
         self.film_woff, self.film_boff = woff_all.to(self.dev), torch.cat(boff).to(self.dev)
         self.c1 = self.p["input_dense.weight"].d.shape[0]
+        self.style_drop = self.STYLE_DROP   # (0.0 = the TextStyleEncoder's Dropout in eval mode: dhg_amd.DiffusionModel's differentiable forward)
         self._pe = {}
         self.tape = None
 
@@ -593,7 +594,7 @@ class TrainModel:
         """TextStyleEncoder.forward (text_style.py:96-110)."""
         n = "text_style_model"
         S = style.d.shape[1]
-        st = t.dropout(style, keep, self.STYLE_DROP)                          # [B, S, 1280]
+        st = t.dropout(style, keep, self.style_drop)                          # [B, S, 1280]
         up = _ViewVar(st, (B * S * 5, st.d.shape[2] // 5))                      # reshape_up(., 5): a pure view of the same rows
         stf = self._ffn(t, up, n + ".style_ffn")
         stf = self._ln_affine(t, stf, sigma, n + ".affine1", B)
@@ -621,7 +622,7 @@ class TrainModel:
         self.check_tokens(text)
         mask = (text == 0).to(torch.float32).to(dev).contiguous()          # create_padding_mask (utils/nn.py:189), host side
         if style_keep is None:
-            style_keep = (torch.rand(style.shape) >= self.STYLE_DROP).float()
+            style_keep = (torch.rand(style.shape) >= self.style_drop).float()
         return self.forward_device(f(strokes), text.to(dev, torch.int64).contiguous(), mask, f(sigma), f(style), f(style_keep))
 
     def forward_device(self, strokes, ids, mask, sigma, style, keep):
