@@ -733,12 +733,36 @@ class GraphedTrainStep:
         self.shape = (B, L, Lt, S)
         self.sched = (d_model, warmup, lr_mul)
         z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
-        self.x, self.eps, self.pen, self.alphas = z(B, L, 2), z(B, L, 2), z(B, L), z(B)
-        self.sigma, self.ids, self.mask = z(B, 1), torch.zeros(B, Lt, dtype=torch.int64, device=dev), z(B, Lt)
-        self.style, self.keep = z(B, S, 1280), z(B, S, 1280)
-        self.hyper, self.sqnorm, self.out = z(8), z(1), z(3)
+        # Every per-update input lives in ONE device block that a single asynchronous copy from pinned host memory fills (the
+        # separate pageable copies of round 3 — strokes, pen, alphas, sigma, ids, mask, style, hyper, rng: nine host-blocking
+        # transfers — left the GPU idle for ~0.4 ms between two updates, rocprofv3 trace of tools/bench_train.py).  Two pinned
+        # blocks alternate, so the host fills update k + 1's inputs while update k runs.
+        fields = [("ids", (B, Lt), torch.int64), ("rng", (2,), torch.int64), ("x", (B, L, 2), torch.float32), ("pen", (B, L), torch.float32),
+                  ("alphas", (B,), torch.float32), ("sigma", (B, 1), torch.float32), ("mask", (B, Lt), torch.float32),
+                  ("hyper", (8,), torch.float32), ("style", (B, S, 1280), torch.float32)]
+        if not device_rng:
+            fields += [("eps", (B, L, 2), torch.float32), ("keep", (B, S, 1280), torch.float32)]
+        offs, off = {}, 0
+        for name, shape, dt in fields:
+            n = int(np.prod(shape)) * (8 if dt == torch.int64 else 4)
+            offs[name] = (off, n, shape, dt)
+            off += (n + 15) // 16 * 16
+        self._stage_dev = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self._stage_host = [torch.zeros(off, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._stage_ev = [None, None]
+        self._stage_turn = 0
+        carve = lambda buf: {k: buf[o:o + n].view(dt).view(shape) for k, (o, n, shape, dt) in offs.items()}   # noqa: E731
+        self._dv, self._hv = carve(self._stage_dev), [carve(h) for h in self._stage_host]
+        d = self._dv
+        self.x, self.pen, self.alphas, self.sigma, self.ids, self.mask, self.style, self.hyper = (d[k] for k in ("x", "pen", "alphas", "sigma", "ids", "mask", "style", "hyper"))
+        self.eps = d["eps"] if not device_rng else z(B, L, 2)
+        self.keep = d["keep"] if not device_rng else z(B, S, 1280)
+        d["rng"].copy_(model.rng)
+        self.rng = model.rng = d["rng"]      # (the model's dropout sites read the same generator state: one pointer, inside the block)
+        self.sqnorm, self.out = z(1), z(3)
         model.prepare_tables(L, Lt)
         self.graph = None
+        self._opt_in_graph = False
 
     def _body(self):
         """Everything of one update that runs on the device (what the graph holds)."""
@@ -776,32 +800,49 @@ class GraphedTrainStep:
             alphas = get_alphas(B, alpha_set)
         rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        self.rng.copy_(torch.tensor([self.seed, step * world + rank], dtype=torch.int64))
+        turn = self._stage_turn
+        self._stage_turn ^= 1
+        if self._stage_ev[turn] is not None:
+            self._stage_ev[turn].synchronize()       # the copy that last read this pinned block (two updates ago) has finished
+        hv = self._hv[turn]
+        hv["rng"][0], hv["rng"][1] = self.seed, step * world + rank
         if self.device_rng:
             if eps is not None or style_keep is not None:
                 raise ValueError("this step draws eps and the dropout mask on the device (device_rng=True)")
         else:
-            self.eps.copy_(eps if eps is not None else torch.randn(B, L, 2))
-            self.keep.copy_(style_keep if style_keep is not None else (torch.rand(B, S, 1280) >= TrainModel.STYLE_DROP).float())
-        self.x.copy_(strokes3[:, :, :2])
-        self.pen.copy_(strokes3[:, :, 2])
-        self.alphas.copy_(alphas.reshape(B))
-        self.sigma.copy_(torch.sqrt(alphas).reshape(B, 1))
-        self.ids.copy_(batch["text"])
-        self.mask.copy_((batch["text"] == 0).float())
-        self.style.copy_(batch["style"])
-        self.hyper.copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched)), dtype=torch.float32))
+            hv["eps"].copy_(eps if eps is not None else torch.randn(B, L, 2))
+            hv["keep"].copy_(style_keep if style_keep is not None else (torch.rand(B, S, 1280) >= TrainModel.STYLE_DROP).float())
+        hv["x"].copy_(strokes3[:, :, :2])
+        hv["pen"].copy_(strokes3[:, :, 2])
+        hv["alphas"].copy_(alphas.reshape(B))
+        hv["sigma"].copy_(torch.sqrt(alphas).reshape(B, 1))
+        hv["ids"].copy_(batch["text"])
+        hv["mask"].copy_(batch["text"] == 0)
+        hv["style"].copy_(batch["style"])
+        hv["hyper"].copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched)), dtype=torch.float32))
+        self._stage_dev.copy_(self._stage_host[turn], non_blocking=True)
+        ev = self._stage_ev[turn] = self._stage_ev[turn] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.model.dev))
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         if not graph:
             self._body()
-        elif self.graph is None:
-            # loss_kernel accumulates into out[1], out[2] — dhw_train_loss zeroes them itself; capture on torch's capture stream
+            self._apply()
+            return self.out
+        if self.graph is None:
+            # loss_kernel accumulates into out[1], out[2] — dhw_train_loss zeroes them itself; capture on torch's capture stream.
+            # Without a process group there is nothing between the backward and the optimizer: clip + Adam are the graph's last
+            # nodes and an update is ONE launch; with one, the collective stays outside the capture and the optimizer follows it.
+            self._opt_in_graph = not dist_on
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._body()
-            self.graph.replay()
-        else:
-            self.graph.replay()
-        self._apply()
+                if self._opt_in_graph:
+                    self.opt.step_dev(self.model.grads(), self.hyper, self.sqnorm)
+        elif self._opt_in_graph and dist_on:
+            raise RuntimeError("this step was captured without a process group; build a new GraphedTrainStep after init_process_group")
+        self.graph.replay()
+        if not self._opt_in_graph:
+            self._apply()
         return self.out
 
     def grad_norm(self) -> float:
