@@ -194,7 +194,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     commit(0, R2, R2 + KBS * SK);
     lds_barrier();
     int ib = 0;
-    for (int kb = 0; kb < p.Lk; kb += KBS, ++ib) {
+    auto key_block = [&](int kb) {
       const bool more = kb + KBS < p.Lk;
       char* KT = R2 + (DB && (ib & 1) ? BUFB : 0);
       char* VT = KT + KBS * SK;
@@ -212,6 +212,15 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
         lds_barrier();      // next block complete (double buffer: its previous contents were read one iteration ago)
       }
       // (after the last block the barrier behind the a2 store below separates the staging tiles from their next use)
+    };
+    if constexpr (EARLY) {
+      // the first block straight-line, outside the loop: inside it hipcc cannot count the loads in flight (the weight prefetch
+      // above among them) and waits for all of them — vmcnt(0) in front of the first block's math, i.e. the prefetch hid nothing
+      key_block(0);
+      ib = 1;
+      for (int kb = KBS; kb < p.Lk; kb += KBS, ++ib) key_block(kb);
+    } else {
+      for (int kb = 0; kb < p.Lk; kb += KBS, ++ib) key_block(kb);
     }
     if constexpr (PLDS && !PLFIX) {
       // the last block (index ib - 1) was read from buffer (ib - 1) & 1; the other one is free: its readers finished an
