@@ -221,6 +221,7 @@ struct dhw_handle {
   bool chain = true;            // row-local stages continue across layer boundaries inside one launch (env DHW_CHAIN=0 -> off)
   bool fuse = true;             // fused block kernels (env DHW_FUSE=0 -> one launch per GEMM, for A/B runs)
   bool fuse_text = true;        // fused text-side kernels (textside.hip; env DHW_FUSE_TEXT=0 -> generic GEMM / attention launches)
+  int text_pairs = 0;           // (step, prompt) pairs per workgroup of text_layer_kernel: 0 = by size, env DHW_TEXT_PAIRS = 1 / 2 forces one form
   std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
   int64_t* d_text_stage = nullptr;
   float* d_style_stage = nullptr;
@@ -1083,6 +1084,7 @@ void text_style_dynamic(Ctx& c) {
       t.film = c.film; t.film_bs = c.film_bs; t.film_div = c.film_div; t.film_tot = h->film_tot; t.f0 = w.f0;
       t.w_kv = w.w_kv1; t.b_kv = w.b_kv1; t.pb_k1 = w.pb_k1;
       t.k1 = BUF(c, ln + ".k1" + x); t.vt1 = BUF(c, ln + ".vt1" + x); t.lpadT = h->lpadT;
+      t.pairs = h->text_pairs;
       const double n = c.B, dd = w.d;
       Launch l(h, c.st, "enc.text_fused", n * c.Lt * (2.0 * dt * dd + 4.0 * dd * dd), n * c.Lt * (dt + 2.0 * dd) * h->es + (dt * dd + 2.0 * dd * dd) * h->es);
       hipError_t e = launch_text_layer(h->prec, t, c.st);
@@ -1348,6 +1350,7 @@ int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
   if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
   if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
   if (const char* e = getenv("DHW_PERSIST")) h->persist = atoi(e) != 0;
+  if (const char* e = getenv("DHW_TEXT_PAIRS")) h->text_pairs = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
   if (h->padded) h->fuse = false;   // (pad_weights: the fused block kernels have compile-time LayerNorm widths)
   if (!rc && h->prec == PREC_BF16 && h->persist) {
     hipDeviceProp_t prop;

@@ -202,6 +202,7 @@ struct TextLayerParams {
   const float* pb_k1;     // PE·Wk table [>= Lt][d]
   void* k1;               // [n][Lt][d]
   void* vt1; int lpadT;   // v1 [n][Lt][d], rows like k1 (lpadT unused)
+  int pairs;              // pairs per workgroup: 0 = the launcher's choice, 1, 2 (2 needs an even film_div: textside.hip)
 };
 bool textside_supported(int prec, int Lt, int S5, int dt);
 hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st);

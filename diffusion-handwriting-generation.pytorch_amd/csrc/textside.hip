@@ -305,12 +305,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   tile_copy_out<T>(T2, S, reinterpret_cast<T*>(p.text_out) + (size_t)pair * p.Lt * DM, DM, p.Lt, DM, tid, 512);
 }
 
-// ---- the text half of one EncoderLayer for one (step, prompt) pair
-// OCC workgroups per CU (VGPR budget 512 / (2 OCC) per lane, LDS <= 160 / OCC KiB): there are T*B >> 256 independent pairs,
-// so co-resident workgroups in different stages hide each other's stage boundaries.
-template <typename T, int DMO, int OCC = 2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 * OCC))) void text_layer_kernel(const TextLayerParams p) {
-  constexpr int ES = sizeof(T), DI = 384, BM = 32, KCI = DI / 32, KCO = DMO / 32;
+// ---- the text half of one EncoderLayer for PAIRS (step, prompt) pairs
+// PAIRS = 1: two workgroups per CU (VGPR budget 128 per lane, 58 KB LDS): there are T*B >> 256 independent pairs, so co-resident
+// workgroups in different stages hide each other's stage boundaries.  PAIRS = 2 (round 4): ONE workgroup per CU holds two
+// consecutive pairs that share a FiLM row (the same step: film_div even) as rows [0, 32) and [32, 64) of one 64-row tile, so the
+// layer's three weight matrices (0.3-0.9 MB) are streamed through the CU's L1 once per two pairs instead of once per pair — the
+// stream was half of the kernel — with a full-depth ring; per row the arithmetic is the same sequence of MFMAs, so
+// the outputs are bit-identical to PAIRS = 1.  Measured: no difference (what the shared stream saves, the lost co-residency costs):
+// DHW_TEXT_PAIRS=2 only.
+template <typename T, int DMO, int PAIRS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 4 / PAIRS))) void text_layer_kernel(const TextLayerParams p) {
+  constexpr int OCC = 2 / PAIRS;
+  constexpr int ES = sizeof(T), DI = 384, BM = 32 * PAIRS, KCI = DI / 32, KCO = DMO / 32;
   constexpr int WN = (DMO % 128 == 0) ? 8 : 6, NT = DMO / WN / 16, MT = BM / 16;
   constexpr int SI = tile_stride<T>(DI), SO = tile_stride<T>(DMO);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -318,7 +324,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
   char* TL = XS + BM * SI;               // tl [BM][DMO]
   float* red = reinterpret_cast<float*>(TL + BM * SO);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-  const int pair = blockIdx.x;
+  const int pair = blockIdx.x * PAIRS;
+  const int npair = min(PAIRS, p.n - pair);          // (the last workgroup of an odd n holds one pair: its second half stays zero)
   const float* gam = p.film + (long)(pair / p.film_div) * p.film_bs;
   const float* bet = gam + p.film_tot;
   const bool act = WN == 8 || wave < WN;
@@ -328,16 +335,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
   EpiParams<NT> ep;
   {  // text_out rows -> LDS through SiLU (text_dense's input activation, nn.py:165-175)
     const T* src = reinterpret_cast<const T*>(p.text_out) + (size_t)pair * p.Lt * DI;
-    constexpr int cpr = DI * ES / 16;
-    uint4 v[3];
+    constexpr int cpr = DI * ES / 16, NU = BM * cpr / 512;
+    static_assert(BM * cpr % 512 == 0, "staging chunks per thread");
+    uint4 v[NU];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr;
+    for (int u = 0; u < NU; ++u) {
+      const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr, pr = r >> 5, rr = r & 31;
       v[u] = make_uint4(0, 0, 0, 0);
-      if (r < p.Lt) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)r * DI + cc * (16 / ES));
+      if (pr < npair && rr < p.Lt) v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)pr * p.Lt + rr) * DI + cc * (16 / ES));
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr;
       T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
@@ -372,6 +380,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
   }
   lds_barrier();
 
+  // (both pairs' rows, each pair's Lt rows to its own [Lt][DMO] block of the output)
+  auto copy_out = [&](void* base) {
+#pragma unroll
+    for (int pr = 0; pr < PAIRS; ++pr)
+      if (pr < npair) tile_copy_out<T>(XS + pr * 32 * SO, SO, reinterpret_cast<T*>(base) + (size_t)(pair + pr) * p.Lt * DMO, DMO, p.Lt, DMO, tid, 512);
+  };
   const char* lop = TL + l15 * SO + g * 8 * ES;
   {  // ---- k1 = Wk tl + bk + PE·Wk[row] -> coalesced rows
     f32x4 acc[NT][MT];
@@ -384,14 +398,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          const int r = j * 16 + l15;
+          const int r = j * 16 + l15, rr = r & 31;                       // rr: the token's position inside its pair
           f32x4 v = acc[i][j] + ep.bias[i];
-          v += *reinterpret_cast<const f32x4*>(p.pb_k1 + (size_t)(r < p.Lt ? r : p.Lt - 1) * DMO + n0 + 16 * i);   // (clamped, not branched)
+          v += *reinterpret_cast<const f32x4*>(p.pb_k1 + (size_t)(rr < p.Lt ? rr : p.Lt - 1) * DMO + n0 + 16 * i);   // (clamped, not branched)
           store4(reinterpret_cast<T*>(XS + r * SO) + n0 + 16 * i, v);   // (the SiLU(text) tile is dead: two barriers ago)
         }
     }
     lds_barrier();
-    tile_copy_out<T>(XS, SO, reinterpret_cast<T*>(p.k1) + (size_t)pair * p.Lt * DMO, DMO, p.Lt, DMO, tid, 512);
+    copy_out(p.k1);
   }
   {  // ---- v1 = Wv tl + bv (no PE: model.py:46) -> coalesced rows, like k1 (the cross-attention reads V^T with the transposing LDS
      // read: attn_core.h)
@@ -409,14 +423,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 
         for (int j = 0; j < MT; ++j) store4(reinterpret_cast<T*>(XS + (j * 16 + l15) * SO) + n0 + 16 * i, acc[i][j] + ep.bias[i]);
     }
     lds_barrier();
-    tile_copy_out<T>(XS, SO, reinterpret_cast<T*>(p.vt1) + (size_t)pair * p.Lt * DMO, DMO, p.Lt, DMO, tid, 512);
+    copy_out(p.vt1);
   }
 }
 
 constexpr size_t text_style_lds() { return (size_t)80 * tile_stride<bf16_t>(384) + (size_t)384 * (80 * 2 + 16) + (size_t)32 * tile_stride<bf16_t>(384) + 2 * 8 * 32 * sizeof(float); }
-template <int DMO>
+template <int DMO, int PAIRS>
 constexpr size_t text_layer_lds() {
-  return (size_t)32 * tile_stride<bf16_t>(384) + (size_t)32 * tile_stride<bf16_t>(DMO) + 2 * 8 * 32 * sizeof(float);
+  return (size_t)32 * PAIRS * tile_stride<bf16_t>(384) + (size_t)32 * PAIRS * tile_stride<bf16_t>(DMO) + 2 * 8 * 32 * PAIRS * sizeof(float);
 }
 
 }  // namespace
@@ -425,9 +439,11 @@ hipError_t textside_init() {
   static_assert(text_style_lds() <= 160 * 1024, "text_style tile does not fit LDS");
   hipError_t e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(text_style_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(text_layer_kernel<bf16_t, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(text_layer_kernel<bf16_t, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(text_layer_kernel<bf16_t, 384>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define DHW_TL_ATTR(D_, P_) if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(text_layer_kernel<bf16_t, D_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e
+  DHW_TL_ATTR(192, 1); DHW_TL_ATTR(256, 1); DHW_TL_ATTR(384, 1);
+  DHW_TL_ATTR(192, 2); DHW_TL_ATTR(256, 2); DHW_TL_ATTR(384, 2);
+#undef DHW_TL_ATTR
+  return hipSuccess;
 }
 
 bool textside_supported(int prec, int Lt, int S5, int dt) { return prec == PREC_BF16 && Lt >= 1 && Lt <= 32 && S5 >= 1 && S5 <= 80 && dt == 384; }
@@ -440,11 +456,17 @@ hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st)
 
 hipError_t launch_text_layer(int prec, const TextLayerParams& p, hipStream_t st) {
   if (prec != PREC_BF16 || p.Lt < 1 || p.Lt > 32 || p.n < 1 || p.film_div < 1 || p.lpadT < 32 || p.lpadT % 8) return hipErrorInvalidValue;
+  // two pairs per workgroup where consecutive pairs share their FiLM row (the all-steps text plane with an even batch) (p.pairs: dhw_create's DHW_TEXT_PAIRS = 1 / 2 forces either form; A/B, equivalence test)
+  const bool two = p.film_div % 2 == 0 && p.pairs == 2;   // (measured equal: 18.72 vs 18.73 ms per 60-step batch, profiles/r04_text_pairs_ab.log — off unless forced)
+#define DHW_TL_LAUNCH(D_) \
+  if (two) hipLaunchKernelGGL((text_layer_kernel<bf16_t, D_, 2>), dim3((p.n + 1) / 2), dim3(512), (text_layer_lds<D_, 2>()), st, p); \
+  else hipLaunchKernelGGL((text_layer_kernel<bf16_t, D_, 1>), dim3(p.n), dim3(512), (text_layer_lds<D_, 1>()), st, p)
   switch (p.d) {
-    case 192: hipLaunchKernelGGL((text_layer_kernel<bf16_t, 192>), dim3(p.n), dim3(512), text_layer_lds<192>(), st, p); break;
-    case 256: hipLaunchKernelGGL((text_layer_kernel<bf16_t, 256>), dim3(p.n), dim3(512), text_layer_lds<256>(), st, p); break;
-    case 384: hipLaunchKernelGGL((text_layer_kernel<bf16_t, 384>), dim3(p.n), dim3(512), text_layer_lds<384>(), st, p); break;
+    case 192: DHW_TL_LAUNCH(192); break;
+    case 256: DHW_TL_LAUNCH(256); break;
+    case 384: DHW_TL_LAUNCH(384); break;
     default: return hipErrorInvalidValue;
   }
+#undef DHW_TL_LAUNCH
   return hipGetLastError();
 }

@@ -356,6 +356,17 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
 
 
+def test_two_text_pairs_per_workgroup_give_the_same_bits():
+    """text_layer_kernel holds two (step, prompt) pairs of the all-steps text plane per workgroup when they share a FiLM row (even
+    batch): one weight stream for both.  Same MFMA sequence per row => identical samples; forced on here (the launcher's own choice
+    needs >= 1024 pairs) against one pair per workgroup, at an even batch whose pairs fill whole and half tiles (Lt = 9 of 32 rows)."""
+    B, L, Lt, T = 4, 80, 9, 5
+    inp = spec.synthetic_inputs(B, L, Lt, seed=17, pad=2, T=T)
+    tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
+    outs = [dhg_amd.sample(_fresh_model("bf16", {"DHW_TEXT_PAIRS": v}, B=B, L=L, Lt=Lt), tx, sv, L=L, T=T, noise=nz).cpu() for v in ("1", "2")]
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_long_sequence_config_matches_oracle():
     """BASELINE configs[3] shape class (L=1000, 62 tokens) with a short schedule: exercises multi-block attention
     (L/2 = 500 keys), several row tiles per sample at every level and the T-generalised schedule."""
