@@ -59,9 +59,27 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* eps, const float
 __global__ void loss_finish_kernel(float* out) { out[0] = out[1] + out[2]; }
 
 // sum of squares of a flat buffer -> *out (atomic), for the global gradient norm (clip_grad.py:42-43, torch clip_grad_norm_)
+// (16-byte loads, four independent partial sums per lane: 40 MB in ~10 us; the one-float-per-lane loop took 28)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, float* out) {
   float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  const long stride = (long)gridDim.x * 256, t = (long)blockIdx.x * 256 + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    const long n4 = n / 4;
+    f32x4 a = (f32x4){0, 0, 0, 0}, b = a;
+    long i = t;
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 u = g4[i], v = g4[i + stride];
+      a += u * u;
+      b += v * v;
+    }
+    if (i < n4) { const f32x4 u = g4[i]; a += u * u; }
+    a += b;
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+    for (long k = n4 * 4 + t; k < n; k += stride) s += g[k] * g[k];
+  } else {
+    for (long i = t; i < n; i += stride) s += g[i] * g[i];
+  }
   __shared__ float r[4];
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
@@ -1061,6 +1079,139 @@ __global__ __launch_bounds__(256) void ln_film_bwd_kernel(const float* dy, const
   }
 }
 
+// ---- 16-byte forms of the three passes above (round 4): C % 4 == 0, C <= 512, every pointer and row 16-byte aligned (the launchers
+// check and fall back).  A lane holds channels 4 * lane + 256 * k .. + 3 (k < 2), a row is read once into registers; the scalar forms
+// moved 4 bytes per lane and instruction and re-read the row for each of LayerNorm's passes (8-10 us per launch against 5-6 us of
+// memory time, rocprofv3 trace of tools/bench_train.py).  Same element-wise arithmetic; the reductions associate differently.
+DHW_DEV float sum4(const f32x4& v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+DHW_DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__global__ __launch_bounds__(256) void ln_film_fwd4_kernel(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L,
+                                                            const float* addend, float* y, float* act_out, const float* pe, float* pe_out, float* mean_out, float* rstd_out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const long pb = (row / L) * pstride;
+  f32x4 v[2];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = 4 * lane + 256 * k;
+    v[k] = c < C ? ld4(x + row * C + c) : (f32x4){0, 0, 0, 0};
+    s += sum4(v[k]);
+  }
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (4 * lane + 256 * k < C) { const f32x4 d = v[k] - mean; q += sum4(d * d); }
+  for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / C + 1e-6f);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = 4 * lane + 256 * k;
+    if (c < C) {
+      f32x4 o = (v[k] - mean) * rstd * ld4(gam + pb + c) + ld4(bet + pb + c);
+      if (addend) o += ld4(addend + row * C + c);
+      *reinterpret_cast<f32x4*>(y + row * C + c) = o;
+      if (act_out) *reinterpret_cast<f32x4*>(act_out + row * C + c) = (f32x4){silu_f(o[0]), silu_f(o[1]), silu_f(o[2]), silu_f(o[3])};
+      if (pe_out) *reinterpret_cast<f32x4*>(pe_out + row * C + c) = o + ld4(pe + (row % L) * C + c);
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+__global__ __launch_bounds__(256) void ln_film_bwd4_kernel(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride,
+                                                            int L, int C, float* dx, int accumulate, float* dgam, float* dbet) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+  const int l0 = blockIdx.x * 8, l1 = min(L, l0 + 8);
+  const f32x4 z4 = (f32x4){0, 0, 0, 0};
+  f32x4 sg[2] = {z4, z4}, sb[2] = {z4, z4}, ga[2];
+  bool in[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    in[k] = 4 * lane + 256 * k < C;
+    ga[k] = in[k] ? ld4(gam + b * pstride + 4 * lane + 256 * k) : z4;
+  }
+  for (int l = l0 + w; l < l1; l += 4) {
+    const long row = (long)b * L + l;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xn[2], dn[2];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = 4 * lane + 256 * k;
+      const f32x4 d = in[k] ? ld4(dy + row * C + c) : z4;
+      xn[k] = in[k] ? (ld4(x + row * C + c) - mu) * rs : z4;
+      dn[k] = d * ga[k];
+      sg[k] += d * xn[k];
+      sb[k] += d;
+      s1 += sum4(dn[k]);
+      s2 += sum4(dn[k] * xn[k]);
+    }
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= C; s2 /= C;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = 4 * lane + 256 * k;
+      if (in[k]) {
+        f32x4 v = rs * (dn[k] - s1 - xn[k] * s2);
+        if (accumulate) v += ld4(dx + row * C + c);
+        *reinterpret_cast<f32x4*>(dx + row * C + c) = v;
+      }
+    }
+  }
+  __shared__ __attribute__((aligned(16))) float red[2][4][512];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    *reinterpret_cast<f32x4*>(&red[0][w][4 * lane + 256 * k]) = sg[k];
+    *reinterpret_cast<f32x4*>(&red[1][w][4 * lane + 256 * k]) = sb[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgam + b * pstride + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbet + b * pstride + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// (block = 16 lanes x 4 channels = 64 channels, 16 row groups over a 64-row chunk of one sample)
+__global__ __launch_bounds__(256) void film_act_bwd4_kernel(const float* d, const float* u, const float* gam, const float* bet, long pstride, int L, int C,
+                                                             int act, float* du, int accumulate, float* dgam, float* dbet) {
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 64 + 4 * cl, b = blockIdx.y;
+  const int l0 = blockIdx.z * 64, l1 = min(L, l0 + 64);
+  f32x4 sg = (f32x4){0, 0, 0, 0}, sb = sg;
+  if (c < C) {
+    const f32x4 ga = ld4(gam + b * pstride + c), be = ld4(bet + b * pstride + c);
+    for (int l = l0 + rg; l < l1; l += 16) {
+      const long e = ((long)b * L + l) * C + c;
+      const f32x4 x = ld4(u + e);
+      f32x4 dd = ld4(d + e);
+      if (act) {
+        const f32x4 a = x * ga + be;
+        dd *= (f32x4){dsilu_f(a[0]), dsilu_f(a[1]), dsilu_f(a[2]), dsilu_f(a[3])};
+      }
+      sg += dd * x;
+      sb += dd;
+      f32x4 o = dd * ga;
+      if (accumulate) o += ld4(du + e);
+      *reinterpret_cast<f32x4*>(du + e) = o;
+    }
+  }
+  __shared__ __attribute__((aligned(16))) float rs[16][64], rb[16][64];
+  *reinterpret_cast<f32x4*>(&rs[rg][4 * cl]) = sg;
+  *reinterpret_cast<f32x4*>(&rb[rg][4 * cl]) = sb;
+  __syncthreads();
+  const int x = threadIdx.x;
+  if (x < 64 && blockIdx.x * 64 + x < C) {
+    float a = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a += rs[r][x]; bsum += rb[r][x]; }
+    atomicAdd(dgam + b * pstride + blockIdx.x * 64 + x, a);
+    atomicAdd(dbet + b * pstride + blockIdx.x * 64 + x, bsum);
+  }
+}
+
 // All AffineTransformLayers' gamma / beta Linears (conditioning.py:16-18; 76 Linears of 32 inputs for num_layers = 2) as
 // ONE launch each way.  Column j of the table film[B][TOT] belongs to output channel woff[j] / 32 of some Linear: its weight
 // row starts at flat[woff[j]] (32 floats), its bias is flat[boff[j]] — the parameters stay where the state_dict puts them.
@@ -1203,6 +1354,15 @@ hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, lo
   hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
   return hipGetLastError();
 }
+// the 16-byte kernels' precondition: whole f32x4 per lane (C, the table's row stride) and 16-byte aligned bases (null = absent).
+// DHW_TRAIN_VEC4=0: the scalar forms everywhere (A/B)
+static bool vec4_ok(int C, long pstride, std::initializer_list<const void*> ptrs) {
+  static const bool off = [] { const char* e = getenv("DHW_TRAIN_VEC4"); return e && atoi(e) == 0; }();
+  if (off || C % 4 || pstride % 4) return false;
+  for (const void* q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+  return true;
+}
 hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, const float* addend, float* y,
                                hipStream_t st) {
   const long n4 = (long)B * L * C / 4;
@@ -1211,17 +1371,26 @@ hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* be
 }
 hipError_t launch_film_act_bwd(const float* d, const float* u, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, float* du,
                                int accumulate, float* dgam, float* dbet, hipStream_t st) {
-  hipLaunchKernelGGL(film_act_bwd_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, bet, pstride, L, C, act, du, accumulate, dgam, dbet);
+  if (vec4_ok(C, pstride, {d, u, gam, bet, du}))
+    hipLaunchKernelGGL(film_act_bwd4_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, bet, pstride, L, C, act, du, accumulate, dgam, dbet);
+  else
+    hipLaunchKernelGGL(film_act_bwd_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, bet, pstride, L, C, act, du, accumulate, dgam, dbet);
   return hipGetLastError();
 }
 hipError_t launch_ln_film_fwd(const float* x, long rows, int C, const float* gam, const float* bet, long pstride, int L, const float* addend, float* y,
                               float* act_out, const float* pe, float* pe_out, float* mean, float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, pe, pe_out, mean, rstd);
+  if (C <= 512 && vec4_ok(C, pstride, {x, gam, bet, addend, y, act_out, pe, pe_out}))
+    hipLaunchKernelGGL(ln_film_fwd4_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, pe, pe_out, mean, rstd);
+  else
+    hipLaunchKernelGGL(ln_film_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, x, rows, C, gam, bet, pstride, L, addend, y, act_out, pe, pe_out, mean, rstd);
   return hipGetLastError();
 }
 hipError_t launch_ln_film_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gam, long pstride, int B, int L, int C,
                               float* dx, int accumulate, float* dgam, float* dbet, hipStream_t st) {
-  hipLaunchKernelGGL(ln_film_bwd_kernel, dim3(nb(L, 8), B), dim3(256), 0, st, dy, x, mean, rstd, gam, pstride, L, C, dx, accumulate, dgam, dbet);
+  if (C <= 512 && vec4_ok(C, pstride, {dy, x, gam, dx}))
+    hipLaunchKernelGGL(ln_film_bwd4_kernel, dim3(nb(L, 8), B), dim3(256), 0, st, dy, x, mean, rstd, gam, pstride, L, C, dx, accumulate, dgam, dbet);
+  else
+    hipLaunchKernelGGL(ln_film_bwd_kernel, dim3(nb(L, 8), B), dim3(256), 0, st, dy, x, mean, rstd, gam, pstride, L, C, dx, accumulate, dgam, dbet);
   return hipGetLastError();
 }
 hipError_t launch_ln_fwd(const float* x, long rows, int C, float* y, float* mean, float* rstd, hipStream_t st) {
