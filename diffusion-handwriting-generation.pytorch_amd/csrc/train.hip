@@ -1212,6 +1212,93 @@ __global__ __launch_bounds__(256) void film_act_bwd4_kernel(const float* d, cons
   }
 }
 
+// ---- 16-byte forms of the one-float-per-thread passes (same precondition: n, C multiples of 4, aligned bases)
+__global__ __launch_bounds__(256) void unary4_kernel(int kind, const float* x, long n4, float* y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = ld4(x + 4 * i);
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = kind == 0 ? silu_f(v[k]) : sigmoid_f(v[k]);
+  *reinterpret_cast<f32x4*>(y + 4 * i) = o;
+}
+__global__ __launch_bounds__(256) void add4_kernel(const float* a, const float* b, long n4, float* out, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = ld4(a + 4 * i);
+  if (b) v += ld4(b + 4 * i);
+  if (accumulate) v += ld4(out + 4 * i);
+  *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+}
+__global__ __launch_bounds__(256) void add_rows4_kernel(const float* x, const float* table, long n4, long per_sample4, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) *reinterpret_cast<f32x4*>(out + 4 * i) = ld4(x + 4 * i) + ld4(table + 4 * (i % per_sample4));
+}
+__global__ __launch_bounds__(256) void mask_mul4_kernel(const float* x, const float* mask, float scale, long n4, float* y, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = ld4(x + 4 * i) * ld4(mask + 4 * i) * scale;
+  if (accumulate) v += ld4(y + 4 * i);
+  *reinterpret_cast<f32x4*>(y + 4 * i) = v;
+}
+// (a block = 256 / (C / 4) whole output rows, a thread = 4 channels of one of them: one 32-bit division per thread)
+__global__ __launch_bounds__(256) void pool4_kernel(int mode, const float* x, int C, long rows, float* y, int accumulate) {
+  const int c4 = C / 4, rpb = 256 / c4, rr = threadIdx.x / c4;
+  const long r = (long)blockIdx.x * rpb + rr;
+  const int c = 4 * (threadIdx.x - rr * c4);
+  if (rr >= rpb || r >= rows) return;
+  f32x4 v;
+  if (mode == 0) v = 0.5f * (ld4(x + (2 * r) * C + c) + ld4(x + (2 * r + 1) * C + c));
+  else if (mode == 1) v = 0.5f * ld4(x + (r / 2) * C + c);
+  else if (mode == 2) v = ld4(x + (r / 2) * C + c);
+  else v = ld4(x + (2 * r) * C + c) + ld4(x + (2 * r + 1) * C + c);
+  if (accumulate) v += ld4(y + r * C + c);
+  *reinterpret_cast<f32x4*>(y + r * C + c) = v;
+}
+// softmax over rows of <= 256 columns held in registers (one exponential per element instead of three evaluations, one read of s)
+__global__ __launch_bounds__(256) void softmax_fwd_r_kernel(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + row * cols;
+  const float* mr = mask ? mask + (row / rows_per_sample) * cols : nullptr;
+  float v[4], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < cols ? sr[c] * scale + (mr ? mr[c] * -1e9f : 0.f) : -INFINITY;
+    mx = fmaxf(mx, v[k]);
+  }
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = lane + 64 * k < cols ? expf(v[k] - mx) : 0.f;
+    sum += v[k];
+  }
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < cols) p[row * cols + lane + 64 * k] = v[k] / sum;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_r_kernel(const float* dp, const float* p, long rows, int cols, float scale, float* ds) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float a[4], b[4], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    a[k] = c < cols ? dp[row * cols + c] : 0.f;
+    b[k] = c < cols ? p[row * cols + c] : 0.f;
+    s += a[k] * b[k];
+  }
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < cols) ds[row * cols + lane + 64 * k] = scale * b[k] * (a[k] - s);
+}
+
 // All AffineTransformLayers' gamma / beta Linears (conditioning.py:16-18; 76 Linears of 32 inputs for num_layers = 2) as
 // ONE launch each way.  Column j of the table film[B][TOT] belongs to output channel woff[j] / 32 of some Linear: its weight
 // row starts at flat[woff[j]] (32 floats), its bias is flat[boff[j]] — the parameters stay where the state_dict puts them.
@@ -1328,8 +1415,18 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   hipLaunchKernelGGL(variants[(cv ? 32 : 0) + (g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, ksplit, kslice);
   return hipGetLastError();
 }
+// the 16-byte kernels' precondition: whole f32x4 per lane (C, the table's row stride) and 16-byte aligned bases (null = absent).
+// DHW_TRAIN_VEC4=0: the scalar forms everywhere (A/B)
+static bool vec4_ok(int C, long pstride, std::initializer_list<const void*> ptrs) {
+  static const bool off = [] { const char* e = getenv("DHW_TRAIN_VEC4"); return e && atoi(e) == 0; }();
+  if (off || C % 4 || pstride % 4) return false;
+  for (const void* q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+  return true;
+}
 hipError_t launch_unary(int kind, const float* x, long n, float* y, hipStream_t st) {
-  hipLaunchKernelGGL(unary_kernel, dim3(nb(n)), dim3(256), 0, st, kind, x, n, y);
+  if (n % 4 == 0 && vec4_ok(4, 0, {x, y})) hipLaunchKernelGGL(unary4_kernel, dim3(nb(n / 4)), dim3(256), 0, st, kind, x, n / 4, y);
+  else hipLaunchKernelGGL(unary_kernel, dim3(nb(n)), dim3(256), 0, st, kind, x, n, y);
   return hipGetLastError();
 }
 hipError_t launch_unary_bwd(int kind, const float* dy, const float* x, long n, float* dx, int accumulate, hipStream_t st) {
@@ -1337,11 +1434,14 @@ hipError_t launch_unary_bwd(int kind, const float* dy, const float* x, long n, f
   return hipGetLastError();
 }
 hipError_t launch_add2(const float* a, const float* b, long n, float* out, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(add_kernel2, dim3(nb(n)), dim3(256), 0, st, a, b, n, out, accumulate);
+  if (n % 4 == 0 && vec4_ok(4, 0, {a, b, out})) hipLaunchKernelGGL(add4_kernel, dim3(nb(n / 4)), dim3(256), 0, st, a, b, n / 4, out, accumulate);
+  else hipLaunchKernelGGL(add_kernel2, dim3(nb(n)), dim3(256), 0, st, a, b, n, out, accumulate);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(const float* x, const float* table, long n, long per_sample, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(add_rows_kernel, dim3(nb(n)), dim3(256), 0, st, x, table, n, per_sample, out);
+  if (n % 4 == 0 && per_sample % 4 == 0 && vec4_ok(4, 0, {x, table, out}))
+    hipLaunchKernelGGL(add_rows4_kernel, dim3(nb(n / 4)), dim3(256), 0, st, x, table, n / 4, per_sample / 4, out);
+  else hipLaunchKernelGGL(add_rows_kernel, dim3(nb(n)), dim3(256), 0, st, x, table, n, per_sample, out);
   return hipGetLastError();
 }
 hipError_t launch_film_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, float* y, hipStream_t st) {
@@ -1353,15 +1453,6 @@ hipError_t launch_film_bwd2(const float* d, const float* u, const float* gam, lo
                             float* dbet, hipStream_t st) {
   hipLaunchKernelGGL(film_bwd2_kernel, dim3(nb(C, 64), B, nb(L, 64)), dim3(256), 0, st, d, u, gam, pstride, L, C, du, accumulate, dgam, dbet);
   return hipGetLastError();
-}
-// the 16-byte kernels' precondition: whole f32x4 per lane (C, the table's row stride) and 16-byte aligned bases (null = absent).
-// DHW_TRAIN_VEC4=0: the scalar forms everywhere (A/B)
-static bool vec4_ok(int C, long pstride, std::initializer_list<const void*> ptrs) {
-  static const bool off = [] { const char* e = getenv("DHW_TRAIN_VEC4"); return e && atoi(e) == 0; }();
-  if (off || C % 4 || pstride % 4) return false;
-  for (const void* q : ptrs)
-    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
-  return true;
 }
 hipError_t launch_film_act_fwd(const float* x, const float* gam, const float* bet, long pstride, int B, int L, int C, int act, const float* addend, float* y,
                                hipStream_t st) {
@@ -1402,15 +1493,19 @@ hipError_t launch_ln_bwd(const float* dy, const float* y, const float* rstd, lon
   return hipGetLastError();
 }
 hipError_t launch_softmax_fwd(const float* s, long rows, int cols, long rows_per_sample, const float* mask, float scale, float* p, hipStream_t st) {
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, s, rows, cols, rows_per_sample, mask, scale, p);
+  if (cols <= 256) hipLaunchKernelGGL(softmax_fwd_r_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, s, rows, cols, rows_per_sample, mask, scale, p);
+  else hipLaunchKernelGGL(softmax_fwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, s, rows, cols, rows_per_sample, mask, scale, p);
   return hipGetLastError();
 }
 hipError_t launch_softmax_bwd(const float* dp, const float* p, long rows, int cols, float scale, float* ds, hipStream_t st) {
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, dp, p, rows, cols, scale, ds);
+  if (cols <= 256) hipLaunchKernelGGL(softmax_bwd_r_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, dp, p, rows, cols, scale, ds);
+  else hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nb(rows, 4)), dim3(256), 0, st, dp, p, rows, cols, scale, ds);
   return hipGetLastError();
 }
 hipError_t launch_pool(int mode, const float* x, long n_out, int C, float* y, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(pool_kernel, dim3(nb(n_out)), dim3(256), 0, st, mode, x, n_out, C, y, accumulate);
+  if (n_out % C == 0 && C <= 1024 && vec4_ok(C, 0, {x, y}))
+    hipLaunchKernelGGL(pool4_kernel, dim3(nb(n_out / C, 256 / (C / 4))), dim3(256), 0, st, mode, x, C, n_out / C, y, accumulate);
+  else hipLaunchKernelGGL(pool_kernel, dim3(nb(n_out)), dim3(256), 0, st, mode, x, n_out, C, y, accumulate);
   return hipGetLastError();
 }
 hipError_t launch_embed(int bwd, const int64_t* ids, const float* src, long n, int C, float* dst, hipStream_t st) {
@@ -1419,6 +1514,7 @@ hipError_t launch_embed(int bwd, const int64_t* ids, const float* src, long n, i
   return hipGetLastError();
 }
 hipError_t launch_mask_mul(const float* x, const float* mask, float scale, long n, float* y, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(mask_mul_kernel, dim3(nb(n)), dim3(256), 0, st, x, mask, scale, n, y, accumulate);
+  if (n % 4 == 0 && vec4_ok(4, 0, {x, mask, y})) hipLaunchKernelGGL(mask_mul4_kernel, dim3(nb(n / 4)), dim3(256), 0, st, x, mask, scale, n / 4, y, accumulate);
+  else hipLaunchKernelGGL(mask_mul_kernel, dim3(nb(n)), dim3(256), 0, st, x, mask, scale, n, y, accumulate);
   return hipGetLastError();
 }
