@@ -271,17 +271,28 @@ int dhw_op_film_table_bwd(const float* dfilm, const float* sigma, const float* f
 
 #define OPCHECK(cond, name) if (!(cond)) return tfail(DHW_ERR_ARG, name ": bad argument")
 
-int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
+static int gemm_from_desc(const dhw_gemm_desc* d, OpGemm& g) {
   OPCHECK(d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->nzo > 0 && d->nzi > 0 && d->lr >= 0 && d->taps >= 1, "dhw_op_gemm");
   if ((d->a_shift || d->b_shift || d->a_tap_shift || d->b_z_shift) && d->lr < 1) return tfail(DHW_ERR_ARG, "dhw_op_gemm: a shift needs lr (rows per sample)");
   if (d->taps > 1 && (d->K % d->taps || (d->K / d->taps) % 32)) return tfail(DHW_ERR_ARG, "dhw_op_gemm: taps > 1 needs K / taps to be a multiple of 32");
-  OpGemm g;
   g.A = d->A; g.sam = d->sam; g.sak = d->sak; g.sazo = d->sazo; g.sazi = d->sazi; g.a_shift = d->a_shift; g.a_tap_shift = d->a_tap_shift;
   g.B = d->B; g.sbk = d->sbk; g.sbn = d->sbn; g.sbzo = d->sbzo; g.sbzi = d->sbzi; g.sbt = d->sbt; g.b_shift = d->b_shift; g.b_z_shift = d->b_z_shift;
   g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
   g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr; g.taps = d->taps;
   g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.act_out = d->act_out; g.dsilu_of = d->dsilu_of; g.stamps = nullptr;
+  return 0;
+}
+int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {
+  OpGemm g;
+  if (int rc = gemm_from_desc(d, g)) return rc;
   THIP(launch_sgemm(g, (hipStream_t)hip_stream));
+  return 0;
+}
+int dhw_op_gemm2(const dhw_gemm_desc* d0, const dhw_gemm_desc* d1, void* hip_stream) {
+  OpGemm g0, g1;
+  if (int rc = gemm_from_desc(d0, g0)) return rc;
+  if (int rc = gemm_from_desc(d1, g1)) return rc;
+  THIP(launch_sgemm_pair(g0, g1, (hipStream_t)hip_stream));
   return 0;
 }
 int dhw_op_unary(int kind, const float* x, long long n, float* y, void* st) {

@@ -426,15 +426,18 @@ DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
 // attention products) compiles without their integer divisions and per-element range tests — the prologue of the general
 // form was ~1400 instructions with 19 divisions, as long as the whole K loop of a K = 128 GEMM.
 #ifdef DHW_STAMPS
-#define SG_STAMP(slot) do { if (g.stamps && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && threadIdx.x == 0) g.stamps[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SG_STAMP(slot) do { if (g.stamps && bx == 0 && by == gy / 2 && bz == 0 && threadIdx.x == 0) g.stamps[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SG_STAMP(slot) do { } while (0)
 #endif
 // GM: rows of the output tile, 64 or 32 (columns: always 64).  32-row tiles are for GEMMs whose 64-row tiling would leave CUs
 // idle (1 600 - 1 920 rows x 384 columns = 150 - 180 workgroups at the attention level): twice the workgroups, half the K-loop
 // work each.
+// The body is a device function of the workgroup's tile coordinates (bx = column tile, by = row tile, bz = batch x K slice; gy =
+// row tiles, for the diagnostics) and of its LDS block, so that one launch can run two independent GEMMs (sgemm_pair_kernel).
+constexpr int SG_BUF = 2 * GT * GS;   // floats per operand buffer (sized for TS = float); a workgroup has two
 template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV, int GM = GT>
-__global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
+DHW_DEV void sgemm_body(const OpGemm& g, int ksplit, int kslice, int bx, int by, int bz, int gy, float* smem) {
   static_assert(GM == 64 || GM == 32, "row tile");
   constexpr int MA = GM / 32;   // 16-row MFMA tiles per wave along M
   SG_STAMP(0);
@@ -448,15 +451,14 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
   constexpr bool AKM = AM && sizeof(TS) == 4, BKM = !BK && sizeof(TS) == 4;
   constexpr int TRK = 66;
   static_assert(GK * TRK <= GT * GS, "a k-major tile fits the operand's half of a buffer");
-  constexpr int BUF = 2 * GT * GS;                                       // floats per buffer (sized for TS = float)
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  constexpr int BUF = SG_BUF;
   TS* As = reinterpret_cast<TS*>(smem);
   TS* Bs = As + GT * TR;
   constexpr int BUFE = BUF * (int)(sizeof(float) / sizeof(TS));          // the same in elements of TS
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, q = lane >> 4;
   // grid: x = column tile, y = row tile, z = batch index * ksplit + K slice (each division only where its divisor is not 1)
-  const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GM;
-  int ks = 0, z = blockIdx.z, zo = z, zi = 0;
+  const int n0 = bx * GT, m0 = by * GM;
+  int ks = 0, z = bz, zo = z, zi = 0;
   if (ksplit > 1) { ks = z % ksplit; z /= ksplit; zo = z; }
   if (g.nzi > 1) { zo = z / g.nzi; zi = z - zo * g.nzi; }
   const float* A = g.A + zo * g.sazo + zi * g.sazi;
@@ -807,6 +809,39 @@ __global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ks
     }
   }
   SG_STAMP(5);
+}
+
+template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV, int GM = GT>
+__global__ __launch_bounds__(256) void sgemm_tiled_kernel(const OpGemm g, int ksplit, int kslice) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * SG_BUF];
+  sgemm_body<AM, BK, AV, BV, TS, CV, GM>(g, ksplit, kslice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
+}
+
+// TWO independent GEMMs in one launch (round 4): workgroups [0, n0) run the first, the rest the second.  A layer's weight-gradient
+// and data-gradient GEMMs (both read dy, neither reads the other's output) were two of the update's 306 GEMM launches each, and
+// every launch of this graph lives >= 4.5 us whatever it computes (the smallest kernels of the trace); as one launch the
+// second GEMM's workgroups also fill the CUs that the first one's split-K tail leaves idle.  VA / VB: SgV<...> below (fp32,
+// 16-byte-load forms).  The first GEMM's workgroups are dispatched first: the longer one (the weight gradient) goes there.
+template <bool AM, bool BK, bool CV, int GM>
+struct SgV {
+  static DHW_DEV void run(const OpGemm& g, int ksplit, int kslice, int bx, int by, int bz, int gy, float* smem) {
+    sgemm_body<AM, BK, true, true, float, CV, GM>(g, ksplit, kslice, bx, by, bz, gy, smem);
+  }
+};
+struct SgGrid { unsigned gx, gy, gz; };
+template <typename VA, typename VB>
+__global__ __launch_bounds__(256) void sgemm_pair_kernel(const OpGemm g0, int ks0, int kl0, SgGrid r0, const OpGemm g1, int ks1, int kl1, SgGrid r1) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * SG_BUF];
+  unsigned id = blockIdx.x;
+  const unsigned n0 = r0.gx * r0.gy * r0.gz;
+  if (id < n0) {
+    const unsigned t = id / r0.gx;
+    VA::run(g0, ks0, kl0, (int)(id - t * r0.gx), (int)(t % r0.gy), (int)(t / r0.gy), (int)r0.gy, smem);
+  } else {
+    id -= n0;
+    const unsigned t = id / r1.gx;
+    VB::run(g1, ks1, kl1, (int)(id - t * r1.gx), (int)(t % r1.gy), (int)(t / r1.gy), (int)r1.gy, smem);
+  }
 }
 
 __global__ __launch_bounds__(256) void unary_kernel(int kind, const float* x, long n, float* y) {
@@ -1394,7 +1429,9 @@ hipError_t launch_film_table(int dir, const float* sigma, const float* flat, con
   }
   return hipGetLastError();
 }
-hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
+// tile / split / load-form choice of one GEMM (shared by the single and the paired launch)
+struct SgPlan { int ksplit, kslice; bool am, bk, av, bv, cv, gm32; dim3 grid; };
+static hipError_t plan_sgemm(const OpGemm& g, SgPlan& pl) {
   if (g.M < 1 || g.N < 1 || g.K < 1 || g.nzo < 1 || g.nzi < 1 || g.taps < 1) return hipErrorInvalidValue;
   if (g.taps > 1 && (g.K % g.taps || (g.K / g.taps) % GK)) return hipErrorInvalidValue;
   const int tiles_m = (g.M + GT - 1) / GT, tiles_n = (g.N + GT - 1) / GT;
@@ -1422,6 +1459,13 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   static const bool novec = [] { const char* e = getenv("DHW_SGEMM_SCALAR"); return e && *e == '1'; }();
   if (novec) av = bv = false;
   const bool cv = g.lr > 0 || g.taps > 1 || g.a_shift || g.a_tap_shift || g.b_shift || g.b_z_shift;
+  // 32-row tiles where the 64-row tiling would leave CUs idle (fp32, 16-byte-load forms, no split-K): DHW_SGEMM_GM32=0 to compare
+  static const bool gm32_on = !(getenv("DHW_SGEMM_GM32") && atoi(getenv("DHW_SGEMM_GM32")) == 0);
+  const bool gm32 = gm32_on && av && bv && !g.bf16 && ksplit == 1 && wgs < 224 && g.M > 32;
+  pl = SgPlan{ksplit, kslice, am, bk, av, bv, cv, gm32, dim3((unsigned)tiles_n, (unsigned)(gm32 ? (g.M + 31) / 32 : tiles_m), (unsigned)(g.nzo * g.nzi * ksplit))};
+  return hipSuccess;
+}
+static hipError_t launch_planned(const OpGemm& g, const SgPlan& pl, hipStream_t st) {
   using KFn = void (*)(const OpGemm, int, int);
 #define DHW_SG4(AM_, BK_, TS_, CV_) sgemm_tiled_kernel<AM_, BK_, false, false, TS_, CV_>, sgemm_tiled_kernel<AM_, BK_, false, true, TS_, CV_>, \
                                     sgemm_tiled_kernel<AM_, BK_, true, false, TS_, CV_>, sgemm_tiled_kernel<AM_, BK_, true, true, TS_, CV_>
@@ -1429,18 +1473,43 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   static const KFn variants[64] = {DHW_SG16(float, false), DHW_SG16(bf16_t, false), DHW_SG16(float, true), DHW_SG16(bf16_t, true)};
 #undef DHW_SG16
 #undef DHW_SG4
-  // 32-row tiles where the 64-row tiling would leave CUs idle (fp32, 16-byte-load forms, no split-K): DHW_SGEMM_GM32=0 to compare
-  static const bool gm32_on = !(getenv("DHW_SGEMM_GM32") && atoi(getenv("DHW_SGEMM_GM32")) == 0);
-  const bool gm32 = gm32_on && av && bv && !g.bf16 && ksplit == 1 && wgs < 224 && g.M > 32;
-  const dim3 grid((unsigned)tiles_n, (unsigned)(gm32 ? (g.M + 31) / 32 : tiles_m), (unsigned)(g.nzo * g.nzi * ksplit)), block(256);
-  if (gm32) {
+  const dim3 block(256);
+  if (pl.gm32) {
 #define DHW_SG32(AM_, BK_) sgemm_tiled_kernel<AM_, BK_, true, true, float, false, 32>, sgemm_tiled_kernel<AM_, BK_, true, true, float, true, 32>
     static const KFn v32[8] = {DHW_SG32(false, false), DHW_SG32(false, true), DHW_SG32(true, false), DHW_SG32(true, true)};
 #undef DHW_SG32
-    hipLaunchKernelGGL(v32[am * 4 + bk * 2 + (cv ? 1 : 0)], grid, block, 0, st, g, ksplit, kslice);
+    hipLaunchKernelGGL(v32[pl.am * 4 + pl.bk * 2 + (pl.cv ? 1 : 0)], pl.grid, block, 0, st, g, pl.ksplit, pl.kslice);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(variants[(cv ? 32 : 0) + (g.bf16 ? 16 : 0) + am * 8 + bk * 4 + av * 2 + bv], grid, block, 0, st, g, ksplit, kslice);
+  hipLaunchKernelGGL(variants[(pl.cv ? 32 : 0) + (g.bf16 ? 16 : 0) + pl.am * 8 + pl.bk * 4 + pl.av * 2 + pl.bv], pl.grid, block, 0, st, g, pl.ksplit, pl.kslice);
+  return hipGetLastError();
+}
+hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
+  SgPlan pl;
+  const hipError_t e = plan_sgemm(g, pl);
+  return e != hipSuccess ? e : launch_planned(g, pl, st);
+}
+// a: a weight gradient (A^T B: m along the lanes of A, n along the lanes of B, 64-row tiles), b: a data gradient (A B with B [K][N]);
+// both fp32 with 16-byte loads.  Anything else, or DHW_SGEMM_PAIR=0: two launches.
+hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st) {
+  SgPlan pa, pb;
+  hipError_t e;
+  if ((e = plan_sgemm(a, pa)) != hipSuccess || (e = plan_sgemm(b, pb)) != hipSuccess) return e;
+  static const bool off = [] { const char* v = getenv("DHW_SGEMM_PAIR"); return v && atoi(v) == 0; }();
+  const bool ok = !off && !a.bf16 && !b.bf16 && !a.stamps && !b.stamps && pa.av && pa.bv && pb.av && pb.bv && pa.am && !pa.bk && !pa.gm32 && !pb.am && !pb.bk;
+  if (!ok) {
+    if ((e = launch_planned(a, pa, st)) != hipSuccess) return e;
+    return launch_planned(b, pb, st);
+  }
+  using PFn = void (*)(const OpGemm, int, int, SgGrid, const OpGemm, int, int, SgGrid);
+#define DHW_SGP(CVA_, CVB_, GMB_) sgemm_pair_kernel<SgV<true, false, CVA_, 64>, SgV<false, false, CVB_, GMB_>>
+  static const PFn pairs[8] = {DHW_SGP(false, false, 64), DHW_SGP(false, false, 32), DHW_SGP(false, true, 64), DHW_SGP(false, true, 32),
+                               DHW_SGP(true, false, 64),  DHW_SGP(true, false, 32),  DHW_SGP(true, true, 64),  DHW_SGP(true, true, 32)};
+#undef DHW_SGP
+  const SgGrid ra{pa.grid.x, pa.grid.y, pa.grid.z}, rb{pb.grid.x, pb.grid.y, pb.grid.z};
+  const unsigned long n = (unsigned long)ra.gx * ra.gy * ra.gz + (unsigned long)rb.gx * rb.gy * rb.gz;
+  if (n > 0x7fffffffUL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pairs[(pa.cv ? 4 : 0) + (pb.cv ? 2 : 0) + (pb.gm32 ? 1 : 0)], dim3((unsigned)n), dim3(256), 0, st, a, pa.ksplit, pa.kslice, ra, b, pb.ksplit, pb.kslice, rb);
   return hipGetLastError();
 }
 // the 16-byte kernels' precondition: whole f32x4 per lane (C, the table's row stride) and 16-byte aligned bases (null = absent).

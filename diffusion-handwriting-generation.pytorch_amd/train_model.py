@@ -76,9 +76,35 @@ class Tape:
     def new(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
 
-    def gemm(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
-             nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
-             rowsum=None, addend=None, act_out=None, dsilu_of=None):
+    def gemm(self, *args, **kw):
+        """One GEMM launch; arguments as ``gemm_desc``."""
+        d = self.gemm_desc(*args, **kw)
+        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
+        self.launches += 1
+
+    def gemm_pair(self, first, second):
+        """Two independent GEMMs — ``first`` / ``second``: (args, kwargs) of ``gemm_desc``, or None — as ONE launch where the
+        library can pair them (dhw_op_gemm2: a layer's weight gradient, first, with its data gradient)."""
+        if first is None or second is None:
+            one = first if second is None else second
+            return self.gemm(*one[0], **one[1])
+        d0, d1 = self.gemm_desc(*first[0], **first[1]), self.gemm_desc(*second[0], **second[1])
+        _tcheck(self.lib.dhw_op_gemm2(C.byref(d0), C.byref(d1), self.st))
+        self.launches += 1 if self._pairable(d0, d1) else 2
+
+    @staticmethod
+    def _pairable(d0, d1) -> bool:
+        """The library's rule (train.hip launch_sgemm_pair), for the launch count this tape reports: fp32, 16-byte-load forms, the
+        first A^T B (m along A's lanes) in 64-row tiles, the second A B with B [K][N]."""
+        if os.environ.get("DHW_SGEMM_PAIR") == "0" or d0.bf16 or d1.bf16:
+            return False
+        wg = abs(d0.sam) < abs(d0.sak) and not abs(d0.sbk) < abs(d0.sbn) and d0.sam == 1 and d0.sbn == 1
+        dg = not abs(d1.sam) < abs(d1.sak) and not abs(d1.sbk) < abs(d1.sbn) and d1.sak == 1 and d1.sbn == 1
+        return bool(wg and dg)
+
+    def gemm_desc(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
+                  nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
+                  rowsum=None, addend=None, act_out=None, dsilu_of=None):
         """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
         Kt = K // taps
 
@@ -99,9 +125,9 @@ class Tape:
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
                           act_out.data_ptr() if act_out is not None else None, addend.data_ptr() if addend is not None else None,
                           dsilu_of.data_ptr() if dsilu_of is not None else None, rowsum.data_ptr() if rowsum is not None else None)
-        _tcheck(self.lib.dhw_op_gemm(C.byref(d), self.st))
-        self.launches += 1
+        d._keep = (A, Bm, Cm, bias, act_out, addend, dsilu_of, rowsum)   # (the operands outlive the descriptor's use)
         self.flops += 2 * M * N * K * nzo * nzi
+        return d
 
     def into(self, v: "Var"):
         """(gradient buffer of v, accumulate flag): the first writer overwrites a fresh buffer, later ones add."""
@@ -162,15 +188,17 @@ class Tape:
 
         def bwd():
             dy = y.g
+            dgrad = None
             if not x.leaf:
                 if x.pre is not None:       # x = SiLU(u): d u (+)= (dy W) * SiLU'(u) in the GEMM's output pass, x's own backward has nothing to do
                     dx, acc = self.into(x.pre)
-                    self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc, dsilu_of=x.pre.d)
+                    dgrad = ((dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N), dict(acc=acc, dsilu_of=x.pre.d))
                 else:
                     dx, acc = self.into(x)
-                    self.gemm(dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N, acc=acc)         # dx (+)= dy W
+                    dgrad = ((dy, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N), dict(acc=acc))         # dx (+)= dy W
             dW, db = W.grad(), b.grad() if b is not None else None
-            self.gemm(dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R, acc=True, rowsum=db)   # dW += dy^T x, db += column sums of dy
+            # dW += dy^T x, db += column sums of dy — in one launch with the data gradient (both read dy, neither the other's output)
+            self.gemm_pair(((dy, 0, 1, N, x.d, 0, K, 1, dW, 0, K, 1, N, K, R), dict(acc=True, rowsum=db)), dgrad)
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
@@ -200,11 +228,11 @@ class Tape:
             fuse = merged and x.pre is not None    # x = SiLU(u): the merged data-gradient GEMM writes d u itself
             dx, acc = self.into(x.pre if fuse else x)
             # dx[r] += sum_t dy[r - (t-1)] W[:, :, t];  dW[:, :, t] += dy^T x[r + (t-1)]
-            if merged:
-                self.gemm(dy, 0, Cout, 1, W.d, 0, sco, sci, dx, 0, Cin, 1, R, Cin, 3 * Cout, acc=acc, taps=3, a_shift=1, a_tap_shift=-1,
-                          sbt=st, lr=L, dsilu_of=x.pre.d if fuse else None)
-                self.gemm(dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, gco, gci, Cout, Cin, R, acc=True, nzi=3, zc=(0, gt), b_shift=-1,
-                          b_z_shift=1, lr=L, rowsum=db)                            # the taps as the inner batch index; db rides along
+            if merged:   # (weight gradient — the taps as the inner batch index, db riding along — and data gradient in one launch)
+                self.gemm_pair(((dy, 0, 1, Cout, x.d, 0, Cin, 1, dW, 0, gco, gci, Cout, Cin, R),
+                                dict(acc=True, nzi=3, zc=(0, gt), b_shift=-1, b_z_shift=1, lr=L, rowsum=db)),
+                               ((dy, 0, Cout, 1, W.d, 0, sco, sci, dx, 0, Cin, 1, R, Cin, 3 * Cout),
+                                dict(acc=acc, taps=3, a_shift=1, a_tap_shift=-1, sbt=st, lr=L, dsilu_of=x.pre.d if fuse else None)))
             else:
                 for t in range(3):
                     self.gemm(dy, 0, Cout, 1, W.d, t * st, sco, sci, dx, 0, Cin, 1, R, Cin, Cout, acc=acc or t > 0, a_shift=1 - t, lr=L)

@@ -106,6 +106,10 @@ typedef struct {
 } dhw_gemm_desc;
 
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
+/* two INDEPENDENT GEMMs (neither reads what the other writes, distinct outputs) as one launch where their forms allow it — a
+   layer's weight gradient (first) and data gradient (second), which both read dy — otherwise as two launches; same results as
+   two dhw_op_gemm calls */
+int dhw_op_gemm2(const dhw_gemm_desc* g0, const dhw_gemm_desc* g1, void* hip_stream);
 /* kind 0: SiLU, 1: sigmoid.  Backward: kind 0 takes the forward INPUT x, kind 1 the forward OUTPUT y. */
 int dhw_op_unary(int kind, const float* x, long long n, float* y, void* hip_stream);
 int dhw_op_unary_bwd(int kind, const float* dy, const float* x_or_y, long long n, float* dx, int accumulate, void* hip_stream);
