@@ -93,6 +93,7 @@ SIGNATURES = {
     "dhw_train_last_error": (C.c_char_p, []),
     "dhw_op_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "dhw_op_gemm2": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _P]),
+    "dhw_op_gemm_group": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _P]),
     "dhw_op_unary": (C.c_int, [C.c_int, _P, _LL, _P, _P]),
     "dhw_op_unary_bwd": (C.c_int, [C.c_int, _P, _P, _LL, _P, C.c_int, _P]),
     "dhw_op_add": (C.c_int, [_P, _P, _LL, _P, C.c_int, _P]),

@@ -241,7 +241,8 @@ struct OpGemm {
   unsigned long long* stamps;   // diagnostics only (tools/bench_sgemm.cpp, -DDHW_STAMPS builds): s_memrealtime of one workgroup's phases, or null
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
-hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st);   // two independent GEMMs, one launch where possible
+hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st, int* launches = nullptr);   // two independent GEMMs, one launch where possible
+hipError_t launch_sgemm_group(const OpGemm* g, int n, hipStream_t st, int* launches = nullptr);            // up to 6 independent GEMMs, one launch where possible
 hipError_t launch_film_table(int dir, const float* sigma, const float* flat, const int64_t* woff, const int64_t* boff, int B, int TOT, float* film,
                              float* gflat, float* dsigma, hipStream_t st);
 hipError_t launch_keep_mask(const uint64_t* rng, int site, long n, int per_sample, float p, float* keep, hipStream_t st);

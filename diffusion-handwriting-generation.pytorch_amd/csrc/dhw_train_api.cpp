@@ -292,8 +292,18 @@ int dhw_op_gemm2(const dhw_gemm_desc* d0, const dhw_gemm_desc* d1, void* hip_str
   OpGemm g0, g1;
   if (int rc = gemm_from_desc(d0, g0)) return rc;
   if (int rc = gemm_from_desc(d1, g1)) return rc;
-  THIP(launch_sgemm_pair(g0, g1, (hipStream_t)hip_stream));
-  return 0;
+  int nl = 2;
+  THIP(launch_sgemm_pair(g0, g1, (hipStream_t)hip_stream, &nl));
+  return nl;
+}
+int dhw_op_gemm_group(const dhw_gemm_desc* d, int n, void* hip_stream) {
+  OPCHECK(d && n >= 1 && n <= 6, "dhw_op_gemm_group");
+  OpGemm g[6];
+  for (int i = 0; i < n; ++i)
+    if (int rc = gemm_from_desc(d + i, g[i])) return rc;
+  int nl = n;
+  THIP(launch_sgemm_group(g, n, (hipStream_t)hip_stream, &nl));
+  return nl;
 }
 int dhw_op_unary(int kind, const float* x, long long n, float* y, void* st) {
   OPCHECK(x && y && n > 0 && (kind == 0 || kind == 1), "dhw_op_unary");

@@ -436,8 +436,8 @@ DHW_DEV float frag_sum(const Frag<bf16_t>& f) {
 // The body is a device function of the workgroup's tile coordinates (bx = column tile, by = row tile, bz = batch x K slice; gy =
 // row tiles, for the diagnostics) and of its LDS block, so that one launch can run two independent GEMMs (sgemm_pair_kernel).
 constexpr int SG_BUF = 2 * GT * GS;   // floats per operand buffer (sized for TS = float); a workgroup has two
-template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV, int GM = GT>
-DHW_DEV void sgemm_body(const OpGemm& g, int ksplit, int kslice, int bx, int by, int bz, int gy, float* smem) {
+template <bool AM, bool BK, bool AV, bool BV, typename TS, bool CV, int GM = GT, typename GD = OpGemm>
+DHW_DEV void sgemm_body(const GD& g, int ksplit, int kslice, int bx, int by, int bz, int gy, float* smem) {
   static_assert(GM == 64 || GM == 32, "row tile");
   constexpr int MA = GM / 32;   // 16-row MFMA tiles per wave along M
   SG_STAMP(0);
@@ -842,6 +842,41 @@ __global__ __launch_bounds__(256) void sgemm_pair_kernel(const OpGemm g0, int ks
     const unsigned t = id / r1.gx;
     VB::run(g1, ks1, kl1, (int)(id - t * r1.gx), (int)(t % r1.gy), (int)(t / r1.gy), (int)r1.gy, smem);
   }
+}
+
+// UP TO SIX independent GEMMs in one launch, any mix of the fp32 16-byte-load forms (the q / k / v projections of an attention
+// and, backward, their three weight- and three data-gradient GEMMs; dV with dP, dQ with dK).  The descriptors travel by value in
+// the kernel-argument segment and are read from there through a constant-address-space pointer (scalar loads, no private copy of
+// the one a workgroup picks); a workgroup finds its GEMM from the cumulative workgroup counts.
+constexpr int SG_MAXG = 6;
+struct SgGroupArgs {
+  OpGemm g[SG_MAXG];
+  int ksplit[SG_MAXG], kslice[SG_MAXG];
+  SgGrid r[SG_MAXG];
+  unsigned end[SG_MAXG];   // cumulative workgroup counts (entries past the last GEMM: the total)
+  int var[SG_MAXG];        // form: ((A^T ? 2 : B^T ? 1 : 0) * 2 + conv) * 2 + (32-row tiles)
+};
+typedef const __attribute__((address_space(4))) SgGroupArgs* SgGroupPtr;
+typedef const __attribute__((address_space(4))) OpGemm SgDescC;
+__global__ __launch_bounds__(256) void sgemm_group_kernel(const SgGroupArgs by_value) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * SG_BUF];
+  SgGroupPtr a = (SgGroupPtr)__builtin_amdgcn_kernarg_segment_ptr();   // = &by_value
+  unsigned id = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 0; k < SG_MAXG - 1; ++k) i += id >= a->end[k] ? 1 : 0;
+  if (i) id -= a->end[i - 1];
+  const unsigned gx = a->r[i].gx, gy = a->r[i].gy, t = id / gx;
+  const int bx = (int)(id - t * gx), by = (int)(t % gy), bz = (int)(t / gy), ks = a->ksplit[i], kl = a->kslice[i];
+  SgDescC& g = a->g[i];
+#define DHW_SGG(V_, AM_, BK_, CV_, GM_) case V_: sgemm_body<AM_, BK_, true, true, float, CV_, GM_, SgDescC>(g, ks, kl, bx, by, bz, (int)gy, smem); break
+  switch (a->var[i]) {
+    DHW_SGG(0, false, false, false, 64); DHW_SGG(1, false, false, false, 32); DHW_SGG(2, false, false, true, 64); DHW_SGG(3, false, false, true, 32);
+    DHW_SGG(4, false, true, false, 64);  DHW_SGG(5, false, true, false, 32);  DHW_SGG(6, false, true, true, 64);  DHW_SGG(7, false, true, true, 32);
+    DHW_SGG(8, true, false, false, 64);  DHW_SGG(9, true, false, false, 32);  DHW_SGG(10, true, false, true, 64); DHW_SGG(11, true, false, true, 32);
+    default: break;
+  }
+#undef DHW_SGG
 }
 
 __global__ __launch_bounds__(256) void unary_kernel(int kind, const float* x, long n, float* y) {
@@ -1491,7 +1526,8 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
 }
 // a: a weight gradient (A^T B: m along the lanes of A, n along the lanes of B, 64-row tiles), b: a data gradient (A B with B [K][N]);
 // both fp32 with 16-byte loads.  Anything else, or DHW_SGEMM_PAIR=0: two launches.
-hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st) {
+hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st, int* launches) {
+  if (launches) *launches = 2;
   SgPlan pa, pb;
   hipError_t e;
   if ((e = plan_sgemm(a, pa)) != hipSuccess || (e = plan_sgemm(b, pb)) != hipSuccess) return e;
@@ -1510,6 +1546,45 @@ hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st) {
   const unsigned long n = (unsigned long)ra.gx * ra.gy * ra.gz + (unsigned long)rb.gx * rb.gy * rb.gz;
   if (n > 0x7fffffffUL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pairs[(pa.cv ? 4 : 0) + (pb.cv ? 2 : 0) + (pb.gm32 ? 1 : 0)], dim3((unsigned)n), dim3(256), 0, st, a, pa.ksplit, pa.kslice, ra, b, pb.ksplit, pb.kslice, rb);
+  if (launches) *launches = 1;
+  return hipGetLastError();
+}
+// n <= SG_MAXG independent GEMMs: one launch when every one of them is an fp32 16-byte-load form (and not A^T B^T), else one by one.
+// DHW_SGEMM_GROUP=0: one by one.
+hipError_t launch_sgemm_group(const OpGemm* g, int n, hipStream_t st, int* launches) {
+  if (n < 1 || n > SG_MAXG) return hipErrorInvalidValue;
+  if (launches) *launches = n;
+  SgPlan pl[SG_MAXG];
+  hipError_t e;
+  static const bool off = [] { const char* v = getenv("DHW_SGEMM_GROUP"); return v && atoi(v) == 0; }();
+  bool ok = !off && n > 1;
+  for (int i = 0; i < n; ++i) {
+    if ((e = plan_sgemm(g[i], pl[i])) != hipSuccess) return e;
+    ok = ok && !g[i].bf16 && !g[i].stamps && pl[i].av && pl[i].bv && !(pl[i].am && pl[i].bk);
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i)
+      if ((e = launch_planned(g[i], pl[i], st)) != hipSuccess) return e;
+    return hipSuccess;
+  }
+  SgGroupArgs a{};
+  unsigned long tot = 0;
+  for (int i = 0; i < SG_MAXG; ++i) {
+    if (i < n) {
+      a.g[i] = g[i];
+      a.ksplit[i] = pl[i].ksplit; a.kslice[i] = pl[i].kslice;
+      a.r[i] = SgGrid{pl[i].grid.x, pl[i].grid.y, pl[i].grid.z};
+      a.var[i] = ((pl[i].am ? 2 : pl[i].bk ? 1 : 0) * 2 + (pl[i].cv ? 1 : 0)) * 2 + (pl[i].gm32 ? 1 : 0);
+      tot += (unsigned long)pl[i].grid.x * pl[i].grid.y * pl[i].grid.z;
+    } else {
+      a.r[i] = SgGrid{1, 1, 1};
+      a.var[i] = -1;
+    }
+    a.end[i] = (unsigned)tot;
+  }
+  if (tot > 0x7fffffffUL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sgemm_group_kernel, dim3((unsigned)tot), dim3(256), 0, st, a);
+  if (launches) *launches = 1;
   return hipGetLastError();
 }
 // the 16-byte kernels' precondition: whole f32x4 per lane (C, the table's row stride) and 16-byte aligned bases (null = absent).

@@ -89,18 +89,21 @@ class Tape:
             one = first if second is None else second
             return self.gemm(*one[0], **one[1])
         d0, d1 = self.gemm_desc(*first[0], **first[1]), self.gemm_desc(*second[0], **second[1])
-        _tcheck(self.lib.dhw_op_gemm2(C.byref(d0), C.byref(d1), self.st))
-        self.launches += 1 if self._pairable(d0, d1) else 2
+        n = self.lib.dhw_op_gemm2(C.byref(d0), C.byref(d1), self.st)     # (returns the launches it issued: 1, or 2 where the forms do not pair)
+        _tcheck(n)
+        self.launches += n
 
-    @staticmethod
-    def _pairable(d0, d1) -> bool:
-        """The library's rule (train.hip launch_sgemm_pair), for the launch count this tape reports: fp32, 16-byte-load forms, the
-        first A^T B (m along A's lanes) in 64-row tiles, the second A B with B [K][N]."""
-        if os.environ.get("DHW_SGEMM_PAIR") == "0" or d0.bf16 or d1.bf16:
-            return False
-        wg = abs(d0.sam) < abs(d0.sak) and not abs(d0.sbk) < abs(d0.sbn) and d0.sam == 1 and d0.sbn == 1
-        dg = not abs(d1.sam) < abs(d1.sak) and not abs(d1.sbk) < abs(d1.sbn) and d1.sak == 1 and d1.sbn == 1
-        return bool(wg and dg)
+    def gemm_group(self, items):
+        """Up to six independent GEMMs — ``items``: (args, kwargs) of ``gemm_desc`` (None entries are skipped), dispatched in that
+        order — as one launch where the library can group them (dhw_op_gemm_group)."""
+        items = [it for it in items if it is not None]
+        if len(items) == 1:
+            return self.gemm(*items[0][0], **items[0][1])
+        descs = [self.gemm_desc(*a, **k) for a, k in items]
+        arr = (_lib.GemmDesc * len(descs))(*descs)
+        n = self.lib.dhw_op_gemm_group(arr, len(descs), self.st)
+        _tcheck(n)
+        self.launches += n
 
     def gemm_desc(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
                   nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
@@ -203,6 +206,42 @@ class Tape:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
         return (y, self._silu_of(y, act)) if silu_out else y
+
+    def linear_group(self, specs):
+        """Independent nn.Linears — ``specs``: [(x, W, b)], e.g. the q / k / v projections of one attention — as ONE launch forward
+        and, backward, one launch for their weight gradients and every data gradient whose destination no other member writes
+        (two projections of the same input add into the same gradient buffer: the second one follows in its own launch)."""
+        def plain(x, W):
+            R, K = x.d.shape
+            return x.pre is None and not x.leaf and not (-(-R // 64) * -(-W.d.shape[0] // 64) < 64 and K >= 512)
+        if len(specs) > 3 or not all(plain(x, W) for x, W, _ in specs):
+            return [self.linear(x, W, b) for x, W, b in specs]
+        ys, items = [], []
+        for x, W, b in specs:
+            (R, K), N = x.d.shape, W.d.shape[0]
+            y = Var(self.new(R, N))
+            ys.append(y)
+            items.append(((x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K), dict(bias=b.d if b is not None else None)))
+        self.gemm_group(items)
+
+        def bwd():
+            live = [(x, W, b, y) for (x, W, b), y in zip(specs, ys) if y.g is not None]
+            group, later, written = [], [], set()
+            for x, W, b, y in live:       # dW += dy^T x, db += column sums of dy
+                (R, K), N = x.d.shape, W.d.shape[0]
+                group.append(((y.g, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R), dict(acc=True, rowsum=b.grad() if b is not None else None)))
+            for x, W, b, y in live:       # dx (+)= dy W
+                (R, K), N = x.d.shape, W.d.shape[0]
+                dx, acc = self.into(x)
+                item = ((y.g, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N), dict(acc=acc))
+                (later if dx.data_ptr() in written else group).append(item)
+                written.add(dx.data_ptr())
+            if group:
+                self.gemm_group(group)
+            for a, k in later:
+                self.gemm(*a, **k)
+        self.steps.append(bwd)
+        return ys
 
     def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False):
         """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
@@ -415,13 +454,17 @@ class Tape:
             do = o.g
             dP = S   # the scores are dead after the softmax: reuse their buffer
             dv, av = self.into(v)
-            self.gemm(P, 0, 1, Lk, do, 0, HD, 1, dv, 0, HD, 1, Lk, D, Lq, acc=av, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)          # dV (+)= P^T dO
-            self.gemm(do, 0, HD, 1, v.d, 0, 1, HD, dP, 0, Lk, 1, Lq, Lk, D, nzo=B, nzi=H, za=zq, zb=zk, zc=zs)               # dP = dO V^T
+            self.gemm_group([((P, 0, 1, Lk, do, 0, HD, 1, dv, 0, HD, 1, Lk, D, Lq), dict(acc=av, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)),     # dV (+)= P^T dO
+                             ((do, 0, HD, 1, v.d, 0, 1, HD, dP, 0, Lk, 1, Lq, Lk, D), dict(nzo=B, nzi=H, za=zq, zb=zk, zc=zs))])          # dP = dO V^T
             self.call("dhw_op_softmax_bwd", dP.data_ptr(), P.data_ptr(), B * H * Lq, Lk, scale, dP.data_ptr())                # dS (in place)
             dq, aq = self.into(q)
-            self.gemm(dP, 0, Lk, 1, k.d, 0, HD, 1, dq, 0, HD, 1, Lq, D, Lk, acc=aq, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)        # dQ (+)= dS K
             dk, ak = self.into(k)
-            self.gemm(dP, 0, 1, Lk, q.d, 0, HD, 1, dk, 0, HD, 1, Lk, D, Lq, acc=ak, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)        # dK (+)= dS^T Q
+            if dq.data_ptr() == dk.data_ptr():   # (q and k are the same tensor's gradient: the two updates of it stay ordered)
+                self.gemm(dP, 0, Lk, 1, k.d, 0, HD, 1, dq, 0, HD, 1, Lq, D, Lk, acc=aq, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)
+                self.gemm(dP, 0, 1, Lk, q.d, 0, HD, 1, dk, 0, HD, 1, Lk, D, Lq, acc=1, nzo=B, nzi=H, za=zs, zb=zq, zc=zk)
+            else:
+                self.gemm_group([((dP, 0, Lk, 1, k.d, 0, HD, 1, dq, 0, HD, 1, Lq, D, Lk), dict(acc=aq, nzo=B, nzi=H, za=zs, zb=zk, zc=zq)),   # dQ (+)= dS K
+                                 ((dP, 0, 1, Lk, q.d, 0, HD, 1, dk, 0, HD, 1, Lk, D, Lq), dict(acc=ak, nzo=B, nzi=H, za=zs, zb=zq, zc=zk))])  # dK (+)= dS^T Q
         self.record(o, bwd)
         return o
 
@@ -576,8 +619,8 @@ class TrainModel:
         return t.ln_film_cols(x, self._film, *self.film_cols[name], B, addend, silu_out, pe)
 
     def _mha(self, t, q, k, v, name, B, H, mask=None, addend=None):
-        o = t.attention(self._lin(t, q, name + ".wq"), self._lin(t, k, name + ".wk"), self._lin(t, v, name + ".wv"), B, H, mask)
-        return self._lin(t, o, name + ".dense", addend)
+        qp, kp, vp = t.linear_group([(x, self.p[f"{name}.{w}.weight"], self.p[f"{name}.{w}.bias"]) for x, w in ((q, "wq"), (k, "wk"), (v, "wv"))])
+        return self._lin(t, t.attention(qp, kp, vp, B, H, mask), name + ".dense", addend)
 
     def _convblock(self, t, x, sigma, name, B, L, x_act=None):
         """cnn.py:64-87.  ``x_act``: SiLU(x) where the pass that produced x wrote it already."""

@@ -108,8 +108,11 @@ typedef struct {
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
 /* two INDEPENDENT GEMMs (neither reads what the other writes, distinct outputs) as one launch where their forms allow it — a
    layer's weight gradient (first) and data gradient (second), which both read dy — otherwise as two launches; same results as
-   two dhw_op_gemm calls */
+   two dhw_op_gemm calls.  Returns the number of launches issued (1 or 2), or a negative error code */
 int dhw_op_gemm2(const dhw_gemm_desc* g0, const dhw_gemm_desc* g1, void* hip_stream);
+/* n <= 6 INDEPENDENT GEMMs (g[0..n)), dispatched in that order: one launch where every one is an fp32 16-byte-load form, else n;
+   returns the number of launches issued, or a negative error code */
+int dhw_op_gemm_group(const dhw_gemm_desc* g, int n, void* hip_stream);
 /* kind 0: SiLU, 1: sigmoid.  Backward: kind 0 takes the forward INPUT x, kind 1 the forward OUTPUT y. */
 int dhw_op_unary(int kind, const float* x, long long n, float* y, void* hip_stream);
 int dhw_op_unary_bwd(int kind, const float* dy, const float* x_or_y, long long n, float* dx, int accumulate, void* hip_stream);
