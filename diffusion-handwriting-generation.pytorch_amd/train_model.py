@@ -97,13 +97,16 @@ class Tape:
         """Up to six independent GEMMs — ``items``: (args, kwargs) of ``gemm_desc`` (None entries are skipped), dispatched in that
         order — as one launch where the library can group them (dhw_op_gemm_group)."""
         items = [it for it in items if it is not None]
-        if len(items) == 1:
-            return self.gemm(*items[0][0], **items[0][1])
-        descs = [self.gemm_desc(*a, **k) for a, k in items]
-        arr = (_lib.GemmDesc * len(descs))(*descs)
-        n = self.lib.dhw_op_gemm_group(arr, len(descs), self.st)
-        _tcheck(n)
-        self.launches += n
+        for i in range(0, len(items), 6):
+            chunk = items[i:i + 6]
+            if len(chunk) == 1:
+                self.gemm(*chunk[0][0], **chunk[0][1])
+                continue
+            descs = [self.gemm_desc(*a, **k) for a, k in chunk]
+            arr = (_lib.GemmDesc * len(descs))(*descs)
+            n = self.lib.dhw_op_gemm_group(arr, len(descs), self.st)
+            _tcheck(n)
+            self.launches += n
 
     def gemm_desc(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
                   nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
@@ -213,8 +216,8 @@ class Tape:
         (two projections of the same input add into the same gradient buffer: the second one follows in its own launch)."""
         def plain(x, W):
             R, K = x.d.shape
-            return x.pre is None and not x.leaf and not (-(-R // 64) * -(-W.d.shape[0] // 64) < 64 and K >= 512)
-        if len(specs) > 3 or not all(plain(x, W) for x, W, _ in specs):
+            return not x.leaf and not (-(-R // 64) * -(-W.d.shape[0] // 64) < 64 and K >= 512)
+        if not all(plain(x, W) for x, W, _ in specs):
             return [self.linear(x, W, b) for x, W, b in specs]
         ys, items = [], []
         for x, W, b in specs:
@@ -232,8 +235,8 @@ class Tape:
                 group.append(((y.g, 0, 1, N, x.d, 0, K, 1, W.grad(), 0, K, 1, N, K, R), dict(acc=True, rowsum=b.grad() if b is not None else None)))
             for x, W, b, y in live:       # dx (+)= dy W
                 (R, K), N = x.d.shape, W.d.shape[0]
-                dx, acc = self.into(x)
-                item = ((y.g, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N), dict(acc=acc))
+                dx, acc = self.into(x.pre if x.pre is not None else x)     # (x = SiLU(u): d u straight out of the GEMM's output pass)
+                item = ((y.g, 0, N, 1, W.d, 0, K, 1, dx, 0, K, 1, R, K, N), dict(acc=acc, dsilu_of=x.pre.d if x.pre is not None else None))
                 (later if dx.data_ptr() in written else group).append(item)
                 written.add(dx.data_ptr())
             if group:
@@ -243,7 +246,7 @@ class Tape:
         self.steps.append(bwd)
         return ys
 
-    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False):
+    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False, defer: list | None = None):
         """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
         have any strides: TrainModel keeps the Conv1d weights as [tap][Cout][Cin] in memory (unit stride along Cin), which makes the
         weight the 16-byte-load operand of all three GEMMs; a torch-contiguous W works too (scalar loads, stride-3 stores)."""
@@ -254,8 +257,12 @@ class Tape:
         merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
         act = self.new(R, Cout) if silu_out and merged else None
         if merged:
-            self.gemm(x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin, bias=b.d, taps=3, a_shift=-1, a_tap_shift=1,
-                      sbt=st, lr=L, addend=addend.d if addend is not None else None, act_out=act)
+            fwd = ((x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin),
+                   dict(bias=b.d, taps=3, a_shift=-1, a_tap_shift=1, sbt=st, lr=L, addend=addend.d if addend is not None else None, act_out=act))
+            if defer is not None:      # (the caller launches it together with other independent GEMMs: gemm_group)
+                defer.append(fwd)
+            else:
+                self.gemm(*fwd[0], **fwd[1])
         else:
             for t in range(3):
                 self.gemm(x.d, 0, Cin, 1, W.d, t * st, sci, sco, y.d, 0, Cout, 1, R, Cout, Cin, bias=b.d if t == 0 else None, acc=t > 0,
@@ -624,9 +631,13 @@ class TrainModel:
 
     def _convblock(self, t, x, sigma, name, B, L, x_act=None):
         """cnn.py:64-87.  ``x_act``: SiLU(x) where the pass that produced x wrote it already."""
-        conv = lambda v, n: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L)   # noqa: E731
-        skip = conv(x, "conv_skip")
-        h = self._affine(t, conv(x_act if x_act is not None else t.silu(x), "conv1"), sigma, name + ".affine1", B, act=True)   # SiLU(affine1(.)) in one pass
+        conv = lambda v, n, defer=None: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L, defer=defer)   # noqa: E731
+        xa = x_act if x_act is not None else t.silu(x)
+        both = []                      # conv_skip(x) and conv1(SiLU(x)) are independent: one launch
+        skip, h1 = conv(x, "conv_skip", both), conv(xa, "conv1", both)
+        if both:
+            t.gemm_group(both)
+        h = self._affine(t, h1, sigma, name + ".affine1", B, act=True)   # SiLU(affine1(.)) in one pass
         h = self._affine(t, conv(h, "conv2"), sigma, name + ".affine2", B, act=True)
         return self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B, addend=skip)   # affine3(fc(h)) + conv_skip(x)
 
@@ -643,11 +654,12 @@ class TrainModel:
         self._site += 1
         return t.dropout(v, keep, self.drop_rate)
 
-    def _encoder(self, t, x, text, sigma, mask, name, B, H, pos_factor):
-        """EncoderLayer.forward (model.py:36-58); ``text`` is SiLU(text features) already."""
+    def _encoder(self, t, x, text, sigma, mask, name, B, H, pos_factor, td=None):
+        """EncoderLayer.forward (model.py:36-58); ``text`` is SiLU(text features) already; ``td``: text_dense(text) where the
+        caller has evaluated it (all layers' text_dense in one launch: they share their input)."""
         d = x.d.shape[1]
         Lx, Lt = x.d.shape[0] // B, text.d.shape[0] // B
-        tx, text_pe = self._ln_affine(t, self._lin(t, text, name + ".text_dense"), sigma, name + ".affine0", B, pe=self.pe(Lt, d, 1.0))   # text: SiLU(text features), shared
+        tx, text_pe = self._ln_affine(t, td if td is not None else self._lin(t, text, name + ".text_dense"), sigma, name + ".affine0", B, pe=self.pe(Lt, d, 1.0))   # text: SiLU(text features), shared
         x_pe = t.add_rows(x, self.pe(Lx, d, pos_factor), B)
         x2 = self._mha(t, x_pe, text_pe, tx, name + ".mha", B, H, mask)
         # the residual adds and the positional-encoding adds ride on the passes / GEMMs around them
@@ -710,15 +722,18 @@ class TrainModel:
         self._film_table(t, sigma_v, B)
         txt = t.silu(self._text_style(t, ids, sty, sigma_v, keep, B))                  # SiLU([B*Lt, 2 c2]): every EncoderLayer's text_dense starts
                                                                                        # with it (model.py:38) — once, not once per layer
+        # every EncoderLayer's text_dense (model.py:38) reads the same SiLU(text features): one launch for all of them
+        enc_names = ["enc3", "enc5"] + [f"att_layers.{i}" for i in range(self.num_layers)]
+        td = dict(zip(enc_names, t.linear_group([(txt, self.p[n + ".text_dense.weight"], self.p[n + ".text_dense.bias"]) for n in enc_names])))
         x, xa = self._lin(t, x_in, "input_dense", silu_out=True)
         h1 = self._convblock(t, x, sigma_v, "enc1", B, L, x_act=xa)
         h2 = self._convblock(t, t.resample(0, h1), sigma_v, "enc2", B, L // 2)
-        h2 = self._encoder(t, h2, txt, sigma_v, mask, "enc3", B, 3, 4)
+        h2 = self._encoder(t, h2, txt, sigma_v, mask, "enc3", B, 3, 4, td=td["enc3"])
         h3 = self._convblock(t, t.resample(0, h2), sigma_v, "enc4", B, L // 4)
-        h3 = self._encoder(t, h3, txt, sigma_v, mask, "enc5", B, 4, 2)
+        h3 = self._encoder(t, h3, txt, sigma_v, mask, "enc5", B, 4, 2, td=td["enc5"])
         x = self._lin(t, t.resample(0, h3), "att_dense")
         for i in range(self.num_layers):
-            x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1)
+            x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1, td=td[f"att_layers.{i}"])
         # upsample(x) + skip_conv(h): the add rides on the skip convolution's output pass
         # (and SiLU of the sum, which the decoder block's conv1 starts with, is its second output)
         skip = lambda v, n, Lr, up: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr, addend=up, silu_out=True)   # noqa: E731
