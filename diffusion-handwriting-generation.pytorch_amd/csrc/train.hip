@@ -858,6 +858,7 @@ struct SgGroupArgs {
 };
 typedef const __attribute__((address_space(4))) SgGroupArgs* SgGroupPtr;
 typedef const __attribute__((address_space(4))) OpGemm SgDescC;
+template <typename TS>   // float: exact-f32 MFMA; bf16_t: operands rounded to bf16 at staging (every member of a group has the same mode)
 __global__ __launch_bounds__(256) void sgemm_group_kernel(const SgGroupArgs by_value) {
   __shared__ __attribute__((aligned(16))) float smem[2 * SG_BUF];
   SgGroupPtr a = (SgGroupPtr)__builtin_amdgcn_kernarg_segment_ptr();   // = &by_value
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void sgemm_group_kernel(const SgGroupArgs by_v
   const unsigned gx = a->r[i].gx, gy = a->r[i].gy, t = id / gx;
   const int bx = (int)(id - t * gx), by = (int)(t % gy), bz = (int)(t / gy), ks = a->ksplit[i], kl = a->kslice[i];
   SgDescC& g = a->g[i];
-#define DHW_SGG(V_, AM_, BK_, CV_, GM_) case V_: sgemm_body<AM_, BK_, true, true, float, CV_, GM_, SgDescC>(g, ks, kl, bx, by, bz, (int)gy, smem); break
+#define DHW_SGG(V_, AM_, BK_, CV_, GM_) case V_: sgemm_body<AM_, BK_, true, true, TS, CV_, GM_, SgDescC>(g, ks, kl, bx, by, bz, (int)gy, smem); break
   switch (a->var[i]) {
     DHW_SGG(0, false, false, false, 64); DHW_SGG(1, false, false, false, 32); DHW_SGG(2, false, false, true, 64); DHW_SGG(3, false, false, true, 32);
     DHW_SGG(4, false, true, false, 64);  DHW_SGG(5, false, true, false, 32);  DHW_SGG(6, false, true, true, 64);  DHW_SGG(7, false, true, true, 32);
@@ -1524,6 +1525,7 @@ hipError_t launch_sgemm(const OpGemm& g, hipStream_t st) {
   const hipError_t e = plan_sgemm(g, pl);
   return e != hipSuccess ? e : launch_planned(g, pl, st);
 }
+hipError_t launch_sgemm_group(const OpGemm* g, int n, hipStream_t st, int* launches);
 // a: a weight gradient (A^T B: m along the lanes of A, n along the lanes of B, 64-row tiles), b: a data gradient (A B with B [K][N]);
 // both fp32 with 16-byte loads.  Anything else, or DHW_SGEMM_PAIR=0: two launches.
 hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st, int* launches) {
@@ -1532,6 +1534,10 @@ hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st, i
   hipError_t e;
   if ((e = plan_sgemm(a, pa)) != hipSuccess || (e = plan_sgemm(b, pb)) != hipSuccess) return e;
   static const bool off = [] { const char* v = getenv("DHW_SGEMM_PAIR"); return v && atoi(v) == 0; }();
+  if (!off && a.bf16 && b.bf16) {   // (the mixed-precision mode: through the general grouped kernel)
+    const OpGemm two[2] = {a, b};
+    return launch_sgemm_group(two, 2, st, launches);
+  }
   const bool ok = !off && !a.bf16 && !b.bf16 && !a.stamps && !b.stamps && pa.av && pa.bv && pb.av && pb.bv && pa.am && !pa.bk && !pa.gm32 && !pb.am && !pb.bk;
   if (!ok) {
     if ((e = launch_planned(a, pa, st)) != hipSuccess) return e;
@@ -1560,7 +1566,7 @@ hipError_t launch_sgemm_group(const OpGemm* g, int n, hipStream_t st, int* launc
   bool ok = !off && n > 1;
   for (int i = 0; i < n; ++i) {
     if ((e = plan_sgemm(g[i], pl[i])) != hipSuccess) return e;
-    ok = ok && !g[i].bf16 && !g[i].stamps && pl[i].av && pl[i].bv && !(pl[i].am && pl[i].bk);
+    ok = ok && g[i].bf16 == g[0].bf16 && !g[i].stamps && pl[i].av && pl[i].bv && !(pl[i].am && pl[i].bk) && !(g[i].bf16 && pl[i].gm32);
   }
   if (!ok) {
     for (int i = 0; i < n; ++i)
@@ -1583,7 +1589,8 @@ hipError_t launch_sgemm_group(const OpGemm* g, int n, hipStream_t st, int* launc
     a.end[i] = (unsigned)tot;
   }
   if (tot > 0x7fffffffUL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sgemm_group_kernel, dim3((unsigned)tot), dim3(256), 0, st, a);
+  if (g[0].bf16) hipLaunchKernelGGL(sgemm_group_kernel<bf16_t>, dim3((unsigned)tot), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(sgemm_group_kernel<float>, dim3((unsigned)tot), dim3(256), 0, st, a);
   if (launches) *launches = 1;
   return hipGetLastError();
 }
