@@ -28,7 +28,9 @@ class GemmDesc(C.Structure):   # include/dhw_train.h dhw_gemm_desc
                 ("B", C.c_void_p), ("sbk", C.c_longlong), ("sbn", C.c_longlong), ("sbzo", C.c_longlong), ("sbzi", C.c_longlong), ("sbt", C.c_longlong), ("b_shift", C.c_int), ("b_z_shift", C.c_int),
                 ("C", C.c_void_p), ("scm", C.c_longlong), ("scn", C.c_longlong), ("sczo", C.c_longlong), ("sczi", C.c_longlong),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nzo", C.c_int), ("nzi", C.c_int), ("lr", C.c_int), ("taps", C.c_int),
-                ("bias", C.c_void_p), ("alpha", C.c_float), ("accumulate", C.c_int), ("bf16", C.c_int), ("act_out", C.c_void_p), ("addend", C.c_void_p), ("dsilu_of", C.c_void_p), ("rowsum", C.c_void_p)]
+                ("bias", C.c_void_p), ("alpha", C.c_float), ("accumulate", C.c_int), ("bf16", C.c_int), ("act_out", C.c_void_p), ("addend", C.c_void_p), ("dsilu_of", C.c_void_p), ("rowsum", C.c_void_p),
+                ("film_gamma", C.c_void_p), ("film_beta", C.c_void_p), ("film_pstride", C.c_longlong), ("film_rows", C.c_int), ("film_act", C.c_int),
+                ("film_out", C.c_void_p), ("film_addend", C.c_void_p)]
 
 
 class ConvBlockWeights(C.Structure):   # include/dhw_train.h dhw_convblock_weights (HOST pointers) / dhw_convblock_grads (DEVICE pointers)

@@ -239,6 +239,8 @@ struct OpGemm {
   const float* addend;   // or null: C = alpha A B + bias + addend (C's layout; a residual add in the output pass; no split-K then)
   float* rowsum;   // or null: rowsum[m] += sum_k A(0,m,k) (batch z = 0) — a Linear / Conv1d bias gradient out of its weight-gradient GEMM
   unsigned long long* stamps;   // diagnostics only (tools/bench_sgemm.cpp, -DDHW_STAMPS builds): s_memrealtime of one workgroup's phases, or null
+  // FiLM (+ SiLU) (+ addend) of the value written to C as a further output (film_out null: none); dhw_gemm_desc in include/dhw_train.h
+  const float* film_g = nullptr; const float* film_b = nullptr; long film_ps = 0; int film_rows = 1, film_act = 0; float* film_out = nullptr; const float* film_add = nullptr;
 };
 hipError_t launch_sgemm(const OpGemm& g, hipStream_t st);
 hipError_t launch_sgemm_pair(const OpGemm& a, const OpGemm& b, hipStream_t st, int* launches = nullptr);   // two independent GEMMs, one launch where possible

@@ -280,6 +280,8 @@ static int gemm_from_desc(const dhw_gemm_desc* d, OpGemm& g) {
   g.C = d->C; g.scm = d->scm; g.scn = d->scn; g.sczo = d->sczo; g.sczi = d->sczi;
   g.M = d->M; g.N = d->N; g.K = d->K; g.nzo = d->nzo; g.nzi = d->nzi; g.lr = d->lr; g.taps = d->taps;
   g.bias = d->bias; g.alpha = d->alpha; g.accumulate = d->accumulate; g.bf16 = d->bf16 ? 1 : 0; g.rowsum = d->rowsum; g.addend = d->addend; g.act_out = d->act_out; g.dsilu_of = d->dsilu_of; g.stamps = nullptr;
+  g.film_g = d->film_gamma; g.film_b = d->film_beta; g.film_ps = d->film_pstride; g.film_rows = d->film_rows; g.film_act = d->film_act; g.film_out = d->film_out; g.film_add = d->film_addend;
+  if (g.film_out && (!g.film_g || !g.film_b || g.film_rows < 1 || g.accumulate)) return tfail(DHW_ERR_ARG, "dhw_op_gemm: film_out needs gamma, beta, film_rows >= 1 and accumulate = 0");
   return 0;
 }
 int dhw_op_gemm(const dhw_gemm_desc* d, void* hip_stream) {

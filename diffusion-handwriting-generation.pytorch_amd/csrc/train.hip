@@ -770,8 +770,12 @@ DHW_DEV void sgemm_body(const GD& g, int ksplit, int kslice, int bx, int by, int
   const float* Dd = g.addend ? g.addend + zo * g.sczo + zi * g.sczi : nullptr;   // (ksplit == 1 with an addend / act_out: launch_sgemm)
   float* Ao = g.act_out ? g.act_out + zo * g.sczo + zi * g.sczi : nullptr;
   const float* Du = g.dsilu_of ? g.dsilu_of + zo * g.sczo + zi * g.sczi : nullptr;
+  // FiLM (+ SiLU) (+ addend) of the written value as a further output (unbatched GEMMs: the ConvBlock's convolutions and fc)
+  float* Fo = g.film_out;
+  const float* Fa = g.film_add;
   const bool vec_out = ksplit == 1 && g.scn == 1 && (g.scm & 3) == 0 && m0 + GM <= g.M && n0 + GT <= g.N &&
-                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | reinterpret_cast<uintptr_t>(Ao) | reinterpret_cast<uintptr_t>(Du) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0)) & 15) == 0;   // uniform
+                       ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(Dd) | reinterpret_cast<uintptr_t>(Ao) | reinterpret_cast<uintptr_t>(Du) | (g.bias ? reinterpret_cast<uintptr_t>(g.bias) : 0) |
+                         reinterpret_cast<uintptr_t>(Fo) | reinterpret_cast<uintptr_t>(Fa) | (Fo ? (reinterpret_cast<uintptr_t>(g.film_g) | reinterpret_cast<uintptr_t>(g.film_b) | (uintptr_t)(g.film_ps * 4)) : 0)) & 15) == 0;   // uniform
   if (vec_out) {
     const int c4 = 4 * (t & 15);
     const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + c4) : (f32x4){0, 0, 0, 0};
@@ -787,6 +791,13 @@ DHW_DEV void sgemm_body(const GD& g, int ksplit, int kslice, int bx, int by, int
       }
       *c = g.accumulate ? *c + v : v;
       if (Ao) *reinterpret_cast<f32x4*>(Ao + (long)(m0 + rr) * g.scm + n0 + c4) = (f32x4){silu_f(v[0]), silu_f(v[1]), silu_f(v[2]), silu_f(v[3])};
+      if (Fo) {
+        const long fb = (long)((m0 + rr) / g.film_rows) * g.film_ps + n0 + c4;
+        f32x4 f = v * *reinterpret_cast<const f32x4*>(g.film_g + fb) + *reinterpret_cast<const f32x4*>(g.film_b + fb);
+        if (g.film_act) f = (f32x4){silu_f(f[0]), silu_f(f[1]), silu_f(f[2]), silu_f(f[3])};
+        if (Fa) f += *reinterpret_cast<const f32x4*>(Fa + (long)(m0 + rr) * g.scm + n0 + c4);
+        *reinterpret_cast<f32x4*>(Fo + (long)(m0 + rr) * g.scm + n0 + c4) = f;
+      }
     }
   } else {
     const int n = n0 + lane;
@@ -805,6 +816,13 @@ DHW_DEV void sgemm_body(const GD& g, int ksplit, int kslice, int bx, int by, int
         if (ksplit > 1) atomicAdd(c, v);
         else *c = g.accumulate ? *c + v : v;
         if (Ao) Ao[(long)n * g.scn + (long)m * g.scm] = silu_f(v);
+        if (Fo) {
+          const long fb = (long)(m / g.film_rows) * g.film_ps + n;
+          float f = v * g.film_g[fb] + g.film_b[fb];
+          if (g.film_act) f = silu_f(f);
+          if (Fa) f += Fa[(long)n * g.scn + (long)m * g.scm];
+          Fo[(long)n * g.scn + (long)m * g.scm] = f;
+        }
       }
     }
   }
@@ -1476,7 +1494,7 @@ static hipError_t plan_sgemm(const OpGemm& g, SgPlan& pl) {
   int ksplit = 1;
   static const long sk_target = getenv("DHW_SGEMM_SPLIT_WGS") ? atol(getenv("DHW_SGEMM_SPLIT_WGS")) : 512;   // (two workgroups per CU: 7.6 vs 7.8 ms per update against 256)
   static const long sk_steps = getenv("DHW_SGEMM_SPLIT_STEPS") ? atol(getenv("DHW_SGEMM_SPLIT_STEPS")) : 8;
-  if (g.act_out && g.accumulate) return hipErrorInvalidValue;
+  if ((g.act_out || g.film_out) && g.accumulate) return hipErrorInvalidValue;
   if (g.dsilu_of && (g.bias || g.addend)) return hipErrorInvalidValue;   // (a factor on the product alone)
   if (g.accumulate && !g.addend && !g.dsilu_of && wgs < sk_target && g.K >= 2 * sk_steps * GK) ksplit = (int)std::min<long>((sk_target + wgs - 1) / wgs, g.K / (sk_steps * GK));
   if (ksplit < 1) ksplit = 1;

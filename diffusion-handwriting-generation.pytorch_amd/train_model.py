@@ -32,6 +32,8 @@ _F = 4  # bytes per element
 # main stream's writes into those buffers; the switch and the side stream were removed in round 4.)
 # DHW_TRAIN_FUSE_DSILU=0: SiLU's backward as its own pass again instead of a factor in the consuming GEMM's data-gradient output (A/B)
 FUSE_DSILU = os.environ.get("DHW_TRAIN_FUSE_DSILU", "1") != "0"
+# DHW_TRAIN_FILM_RIDER=0: a ConvBlock's affine (+ SiLU) (+ conv_skip) as its own pass behind the GEMM again instead of a further output of the GEMM (A/B)
+FILM_RIDER = os.environ.get("DHW_TRAIN_FILM_RIDER", "1") != "0"
 
 class Var:
     """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient.  ``leaf``: a network input
@@ -110,8 +112,10 @@ class Tape:
 
     def gemm_desc(self, A, a_off, sam, sak, Bm, b_off, sbk, sbn, Cm, c_off, scm, scn, M, N, K, *, bias=None, alpha=1.0, acc=False,
                   nzo=1, nzi=1, za=(0, 0), zb=(0, 0), zc=(0, 0), a_shift=0, b_shift=0, lr=0, taps=1, a_tap_shift=0, sbt=0, b_z_shift=0,
-                  rowsum=None, addend=None, act_out=None, dsilu_of=None):
-        """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch."""
+                  rowsum=None, addend=None, act_out=None, dsilu_of=None, film=None):
+        """See dhw_gemm_desc (include/dhw_train.h).  Extents are checked here, on the host, before the launch.  ``film``: (gamma
+        pointer, beta pointer, table row stride, rows per sample, act, out tensor, addend tensor or None) — FiLM (+ SiLU) (+ addend)
+        of the written value as a further output of the pass."""
         Kt = K // taps
 
         def extent(off, s0, n0, s1, n1, z, tap_stride=0):
@@ -131,7 +135,13 @@ class Tape:
                           M, N, K, nzo, nzi, lr, taps, bias.data_ptr() if bias is not None else None, alpha, int(acc), self.bf16,
                           act_out.data_ptr() if act_out is not None else None, addend.data_ptr() if addend is not None else None,
                           dsilu_of.data_ptr() if dsilu_of is not None else None, rowsum.data_ptr() if rowsum is not None else None)
-        d._keep = (A, Bm, Cm, bias, act_out, addend, dsilu_of, rowsum)   # (the operands outlive the descriptor's use)
+        if film is not None:
+            fg, fb, fps, frows, fact, fout, fadd = film
+            if fout.numel() != Cm.numel() or scn != 1 or nzo * nzi != 1 or acc:
+                raise ValueError("a FiLM output rides on an unbatched row-major GEMM without accumulation")
+            d.film_gamma, d.film_beta, d.film_pstride, d.film_rows, d.film_act = fg, fb, fps, frows, int(fact)
+            d.film_out, d.film_addend = fout.data_ptr(), fadd.data_ptr() if fadd is not None else None
+        d._keep = (A, Bm, Cm, bias, act_out, addend, dsilu_of, rowsum, film)   # (the operands outlive the descriptor's use)
         self.flops += 2 * M * N * K * nzo * nzi
         return d
 
@@ -175,11 +185,14 @@ class Tape:
         return ya
 
     # ---- differentiable ops ------------------------------------------------------------------------------------------
-    def linear(self, x: Var, W: Var, b: Var | None, addend: Var | None = None, silu_out: bool = False):
+    def linear(self, x: Var, W: Var, b: Var | None, addend: Var | None = None, silu_out: bool = False, film=None):
         """nn.Linear on rows: x [R, K], W [N, K] (torch layout) -> [R, N]; ``addend`` [R, N]: the residual added to the result
-        in the GEMM's output pass (y = x W^T + b + addend)."""
+        in the GEMM's output pass (y = x W^T + b + addend).  ``film`` = (table, col_g, col_b, B, act, addend): returns
+        film_cols(y, ...) instead, evaluated in the same pass."""
         R, K = x.d.shape
         N = W.d.shape[0]
+        if film is not None and -(-R // 64) * -(-N // 64) < 64 and K >= 512:   # (split-K output: the FiLM as its own pass)
+            return self.film_cols(self.linear(x, W, b, addend), *film)
         if (addend is not None or silu_out) and -(-R // 64) * -(-N // 64) < 64 and K >= 512:   # (split-K output: separate passes)
             y = self.linear(x, W, b)
             y = self.add(y, addend) if addend is not None else y
@@ -189,8 +202,9 @@ class Tape:
         split = -(-R // 64) * -(-N // 64) < 64 and K >= 512
         y = Var(torch.zeros(R, N, device=self.dev) if split else self.new(R, N))
         act = self.new(R, N) if silu_out else None     # ``silu_out``: also returns SiLU(y), written by the same GEMM pass
+        fout, frider = self._film_rider(R, N, film) if film is not None else (None, None)
         self.gemm(x.d, 0, K, 1, W.d, 0, 1, K, y.d, 0, N, 1, R, N, K, bias=b.d if b is not None else None, acc=split,
-                  addend=addend.d if addend is not None else None, act_out=act)
+                  addend=addend.d if addend is not None else None, act_out=act, film=frider)
 
         def bwd():
             dy = y.g
@@ -208,6 +222,8 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
+        if film is not None:
+            return self._film_record(y, fout, film)
         return (y, self._silu_of(y, act)) if silu_out else y
 
     def linear_group(self, specs):
@@ -246,7 +262,7 @@ class Tape:
         self.steps.append(bwd)
         return ys
 
-    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False, defer: list | None = None):
+    def conv3(self, x: Var, W: Var, b: Var, L: int, addend: Var | None = None, silu_out: bool = False, defer: list | None = None, film=None):
         """nn.Conv1d(k=3, padding='same') on C-last rows: x [B*L, Cin], W [Cout, Cin, 3] -> [B*L, Cout].  W (and its gradient) may
         have any strides: TrainModel keeps the Conv1d weights as [tap][Cout][Cin] in memory (unit stride along Cin), which makes the
         weight the 16-byte-load operand of all three GEMMs; a torch-contiguous W works too (scalar loads, stride-3 stores)."""
@@ -256,9 +272,10 @@ class Tape:
         y = Var(self.new(R, Cout))
         merged = Cin % 32 == 0 and Cout % 32 == 0      # the three taps as one contraction over K = 3 Cin (dhw_gemm_desc.taps)
         act = self.new(R, Cout) if silu_out and merged else None
+        fout, frider = self._film_rider(R, Cout, film) if film is not None and merged else (None, None)   # (``film``: as in ``linear``)
         if merged:
             fwd = ((x.d, 0, Cin, 1, W.d, 0, sci, sco, y.d, 0, Cout, 1, R, Cout, 3 * Cin),
-                   dict(bias=b.d, taps=3, a_shift=-1, a_tap_shift=1, sbt=st, lr=L, addend=addend.d if addend is not None else None, act_out=act))
+                   dict(bias=b.d, taps=3, a_shift=-1, a_tap_shift=1, sbt=st, lr=L, addend=addend.d if addend is not None else None, act_out=act, film=frider))
             if defer is not None:      # (the caller launches it together with other independent GEMMs: gemm_group)
                 defer.append(fwd)
             else:
@@ -287,6 +304,8 @@ class Tape:
             if addend is not None:
                 self._grad_to(addend, dy)
         self.record(y, bwd)
+        if film is not None:
+            return self._film_record(y, fout, film) if merged else self.film_cols(y, *film)
         if not silu_out:
             return y
         return (y, self._silu_of(y, act)) if act is not None else (y, self.silu(y))
@@ -355,6 +374,32 @@ class Tape:
             dx, acc = self.into(x)
             self.call("dhw_op_film_bwd", y.g.data_ptr(), x.d.data_ptr(), gamma.d.data_ptr(), Cc, B, L, Cc, dx.data_ptr(), acc,
                       gamma.grad().data_ptr(), beta.grad().data_ptr())
+        self.record(y, bwd)
+        return y
+
+    def _film_rider(self, R: int, Cc: int, spec):
+        """``spec`` = (table, col_g, col_b, B, act, addend): the FiLM output tensor of a GEMM that evaluates film_cols in its own
+        output pass, and the ``film`` tuple of ``gemm_desc``."""
+        table, col_g, col_b, B, act, addend = spec
+        out = self.new(R, Cc)
+        base = table.d.data_ptr()
+        return out, (base + col_g * _F, base + col_b * _F, table.d.shape[1], R // B, bool(act), out, addend.d if addend is not None else None)
+
+    def _film_record(self, u: Var, out: torch.Tensor, spec) -> Var:
+        """The backward of a FiLM output that rode on the GEMM producing ``u`` (same closure as film_cols)."""
+        table, col_g, col_b, B, act, addend = spec
+        R, Cc = u.d.shape
+        L, TOT = R // B, table.d.shape[1]
+        base = table.d.data_ptr()
+        y = Var(out)
+
+        def bwd():
+            dx, acc = self.into(u)
+            gbase = table.grad().data_ptr()
+            self.call("dhw_op_film_act_bwd", y.g.data_ptr(), u.d.data_ptr(), base + col_g * _F, base + col_b * _F, TOT, B, L, Cc, int(act),
+                      dx.data_ptr(), acc, gbase + col_g * _F, gbase + col_b * _F)
+            if addend is not None:
+                self._grad_to(addend, y.g)
         self.record(y, bwd)
         return y
 
@@ -631,15 +676,30 @@ class TrainModel:
 
     def _convblock(self, t, x, sigma, name, B, L, x_act=None):
         """cnn.py:64-87.  ``x_act``: SiLU(x) where the pass that produced x wrote it already."""
-        conv = lambda v, n, defer=None: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L, defer=defer)   # noqa: E731
+        if not FILM_RIDER:
+            return self._convblock_passes(t, x, sigma, name, B, L, x_act)
+        # every affine (+ SiLU) (+ conv_skip) rides on the output pass of the GEMM in front of it (dhw_gemm_desc.film_out)
+        film = lambda k, act, addend=None: (self._film, *self.film_cols[f"{name}.affine{k}"], B, act, addend)   # noqa: E731
+        conv = lambda v, n, defer=None, fl=None: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L, defer=defer, film=fl)   # noqa: E731
         xa = x_act if x_act is not None else t.silu(x)
         both = []                      # conv_skip(x) and conv1(SiLU(x)) are independent: one launch
+        skip, h = conv(x, "conv_skip", both), conv(xa, "conv1", both, film(1, True))      # h = SiLU(affine1(conv1(.)))
+        if both:
+            t.gemm_group(both)
+        h = conv(h, "conv2", None, film(2, True))                                           # SiLU(affine2(conv2(.)))
+        return t.linear(h, self.p[name + ".fc.weight"], self.p[name + ".fc.bias"], film=film(3, False, skip))   # affine3(fc(h)) + conv_skip(x)
+
+    def _convblock_passes(self, t, x, sigma, name, B, L, x_act=None):
+        """The same with every affine as its own pass (DHW_TRAIN_FILM_RIDER=0)."""
+        conv = lambda v, n, defer=None: t.conv3(v, self.p[f"{name}.{n}.weight"], self.p[f"{name}.{n}.bias"], L, defer=defer)   # noqa: E731
+        xa = x_act if x_act is not None else t.silu(x)
+        both = []
         skip, h1 = conv(x, "conv_skip", both), conv(xa, "conv1", both)
         if both:
             t.gemm_group(both)
-        h = self._affine(t, h1, sigma, name + ".affine1", B, act=True)   # SiLU(affine1(.)) in one pass
+        h = self._affine(t, h1, sigma, name + ".affine1", B, act=True)
         h = self._affine(t, conv(h, "conv2"), sigma, name + ".affine2", B, act=True)
-        return self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B, addend=skip)   # affine3(fc(h)) + conv_skip(x)
+        return self._affine(t, self._lin(t, h, name + ".fc"), sigma, name + ".affine3", B, addend=skip)
 
     def _drop(self, t, v, B):
         """EncoderLayer.drop (model.py:23): identity at rate 0; otherwise the next caller-supplied keep-mask (parity tests) or a

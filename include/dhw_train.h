@@ -103,6 +103,12 @@ typedef struct {
                       the operand tile as staged for the MFMA: with bf16 = 1 that is dy ROUNDED to bf16 (fp32 accumulation), i.e. the
                       bias gradient carries the same operand rounding as the weight gradient of its layer (relative 2^-9 per term,
                       sqrt(K)-averaged); with bf16 = 0 it is exact fp32.  act_out / addend / dsilu_of are applied in fp32 either way. */
+  /* FiLM (+ SiLU) of the value written to C as a further output of the same pass (appended in round 4; film_out = NULL: none):
+       film_out[m][n] = act(film_gamma[(m / film_rows) * film_pstride + n] * c + film_beta[...]) + film_addend[m][n]
+     with c the value written to C, act = SiLU when film_act, film_addend NULL or laid out as C — a ConvBlock's
+     SiLU(affine(conv(.))) / affine3(fc(.)) + conv_skip(.) (cnn.py:70-86) without a pass of its own.  accumulate must be 0. */
+  const float* film_gamma; const float* film_beta; long long film_pstride; int film_rows; int film_act;
+  float* film_out; const float* film_addend;
 } dhw_gemm_desc;
 
 int dhw_op_gemm(const dhw_gemm_desc* g, void* hip_stream);
