@@ -109,9 +109,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* sqnorm) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
-  float clip = 1.0f;
-  if (max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(*sqnorm) + 1e-6f));
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7], gs = hyper[8];
+  float clip = gs;   // (gs = 1 / world size behind a SUM all-reduce: the averaging costs no pass of its own; 1 otherwise)
+  if (max_norm > 0.f) clip = gs * fminf(1.0f, max_norm / (sqrtf(*sqnorm) * gs + 1e-6f));
   const float gi = g[i] * clip + wd * p[i];
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
   const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;

@@ -89,14 +89,15 @@ class Adam:
         return gn.sqrt()
 
 
-    def hyper(self, lr: float) -> list:
-        """Advance the update counter and return the 8 scalars ``dhw_train_adam_dev`` reads from device memory."""
+    def hyper(self, lr: float, grad_scale: float = 1.0) -> list:
+        """Advance the update counter and return the 9 scalars ``dhw_train_adam_dev`` reads from device memory.  ``grad_scale``:
+        1 / world size when the gradient buffer holds the SUM over ranks (``allreduce_grads(..., average=False)``)."""
         self.step_count += 1
         b1, b2 = self.betas
-        return [lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, self.max_norm]
+        return [lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, self.max_norm, grad_scale]
 
     def step_dev(self, grads, hyper_dev: torch.Tensor, sqnorm_dev: torch.Tensor):
-        """The update with every scalar on the device (``hyper_dev`` = the 8 floats of ``hyper``): no allocation and no
+        """The update with every scalar on the device (``hyper_dev`` = the 9 floats of ``hyper``): no allocation and no
         host synchronisation, so it can sit inside a captured hipGraph.  ``sqnorm_dev`` receives ||g||^2."""
         n = len(self.params)
         dev = self.params[0].device
@@ -106,7 +107,7 @@ class Adam:
                                               sqnorm_dev.data_ptr(), _stream(dev)))
 
 
-def allreduce_grads(flat_grads, world_size: int | None = None):
+def allreduce_grads(flat_grads, world_size: int | None = None, average: bool = True):
     """Data-parallel gradient averaging (BASELINE configs[4]: DDP over 8 GPUs): ONE all-reduce of each flat gradient buffer
     (the whole model is 40.1 MB of fp32 gradients — a single bucket per buffer keeps the ring collective bandwidth-bound on
     the per-link xGMI rate instead of latency-bound), then 1 / world_size.  backend "nccl" is RCCL on ROCm; gloo on CPU."""
@@ -115,8 +116,9 @@ def allreduce_grads(flat_grads, world_size: int | None = None):
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in flat_grads]
     for w in works:
         w.wait()
-    for g in flat_grads:
-        g.div_(ws)
+    if average:          # (``average=False``: the caller folds 1 / world size into its optimizer — Adam.hyper(grad_scale=...))
+        for g in flat_grads:
+            g.div_(ws)
     return flat_grads
 
 

@@ -885,7 +885,7 @@ class GraphedTrainStep:
         # blocks alternate, so the host fills update k + 1's inputs while update k runs.
         fields = [("ids", (B, Lt), torch.int64), ("rng", (2,), torch.int64), ("x", (B, L, 2), torch.float32), ("pen", (B, L), torch.float32),
                   ("alphas", (B,), torch.float32), ("sigma", (B, 1), torch.float32), ("mask", (B, Lt), torch.float32),
-                  ("hyper", (8,), torch.float32), ("style", (B, S, 1280), torch.float32)]
+                  ("hyper", (9,), torch.float32), ("style", (B, S, 1280), torch.float32)]
         if not device_rng:
             fields += [("eps", (B, L, 2), torch.float32), ("keep", (B, S, 1280), torch.float32)]
         offs, off = {}, 0
@@ -933,7 +933,7 @@ class GraphedTrainStep:
         launches, issued eagerly after the graph so that the collective stays outside the capture."""
         m = self.model
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
-            allreduce_grads(m.grads())
+            allreduce_grads(m.grads(), average=False)      # SUM; Adam applies 1 / world size (hyper[8]) in its own pass
         self.opt.step_dev(m.grads(), self.hyper, self.sqnorm)
 
     def __call__(self, batch: dict, alpha_set, step: int, *, eps=None, alphas=None, style_keep=None, graph: bool = True):
@@ -965,7 +965,8 @@ class GraphedTrainStep:
         hv["ids"].copy_(batch["text"])
         hv["mask"].copy_(batch["text"] == 0)
         hv["style"].copy_(batch["style"])
-        hv["hyper"].copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched)), dtype=torch.float32))
+        hv["hyper"].copy_(torch.tensor(self.opt.hyper(noam_lr(step, *self.sched), 1.0 / world), dtype=torch.float32))
+        self._gscale = 1.0 / world
         self._stage_dev.copy_(self._stage_host[turn], non_blocking=True)
         ev = self._stage_ev[turn] = self._stage_ev[turn] or torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.model.dev))
@@ -993,7 +994,7 @@ class GraphedTrainStep:
 
     def grad_norm(self) -> float:
         """||g|| of the last update before clipping (one host synchronisation)."""
-        return float(self.sqnorm.sqrt())
+        return float(self.sqnorm.sqrt()) * getattr(self, "_gscale", 1.0)
 
 
 def read_train_config(config_path) -> dict:

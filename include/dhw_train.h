@@ -42,8 +42,10 @@ int dhw_train_adam(int nbuf, float* const* p, const float* const* g, float* cons
                    float* grad_norm_out /* device, 1 float, or NULL */, void* hip_stream);
 
 /* The same update with nothing on the host's critical path, for capture into a hipGraph: the scalars come from DEVICE memory
- * hyper[8] = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^step, 1 - beta2^step, max_norm (<= 0: no clipping)} and the
- * squared global gradient norm is left in sqnorm (device, 1 float).  No allocation, no synchronisation. */
+ * hyper[9] = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^step, 1 - beta2^step, max_norm (<= 0: no clipping), grad_scale} and the
+ * squared global norm of the gradient BUFFER is left in sqnorm (device, 1 float).  grad_scale: the gradient is grad_scale * g — 1 /
+ * world_size after a SUM all-reduce, so that no separate pass divides the buffer (norm and clip use the scaled gradient).  No
+ * allocation, no synchronisation. */
 int dhw_train_adam_dev(int nbuf, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
                        const float* hyper, float* sqnorm, void* hip_stream);
 
