@@ -311,7 +311,7 @@ hipError_t launch_loss(const float* eps, const float* pred, const float* pen, co
   return hipGetLastError();
 }
 hipError_t launch_sqnorm(const float* g, long n, float* out, hipStream_t st) {   // out must be zeroed by the caller (several buffers add up)
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(std::min<unsigned>(nb(n), 1024u)), dim3(256), 0, st, g, n, out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(std::min<unsigned>(nb(n), 2048u)), dim3(256), 0, st, g, n, out);
   return hipGetLastError();
 }
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(256) void film_table_wgrad_kernel(const float* dfil
 // dsigma[b][k] += sum_j dfilm[b][j] W[j][k]: block = FTD columns for 32 samples; the weight rows of the chunk ([FTD][32]) and the
 // dfilm tile ([32][FTD]) through LDS once, a thread = (sample, 4 of the 32 k), four atomics per thread.  (One block per (sample,
 // chunk) re-read the chunk's weight rows for every sample: 76 MB of L2 reads for a 2.4 MB matrix, 19 us.)
-constexpr int FTD = 128;
+constexpr int FTD = 64;   // (290 workgroups for the 18 560 columns of num_layers = 2: every CU gets one)
 __global__ __launch_bounds__(256) void film_table_dgrad_kernel(const float* dfilm, const float* flat, const int64_t* woff, int B, int TOT, float* dsigma) {
   __shared__ __attribute__((aligned(16))) float W[FTD][36];
   __shared__ float df[32][FTD + 1];
