@@ -137,18 +137,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       pp = (unsigned long long)(const AS4 void*)&P;
       PTRACE(1);
     }
+#ifdef DHW_PERSIST_ONLY   // diagnostics: a kernel that holds ONLY the bodies in this bit mask (the other phases complete at once):
+                          // what a body costs inside the launch when it is not compiled together with the ten others
+#define PK_ON(k) (((DHW_PERSIST_ONLY) >> (k)) & 1)
+#else
+#define PK_ON(k) 1
+#endif
     switch (kind) {
-      case PK_CONV_ENC1: phase_conv<128, 128, 0, 0, 128>(pp, b, m0, smem); break;
-      case PK_CONV_ENC2A: phase_conv<64, 192, 0, 1, 128>(pp, b, m0, smem); break;
-      case PK_BC192: phase_bc<192, 64, 0>(pp, b, m0, smem); break;
-      case PK_CONV_ENC4: phase_conv<48, 256, 0, 0, 192>(pp, b, m0, smem); break;
-      case PK_A256: phase_a<256, 32>(pp, b, m0, smem); break;
-      case PK_BC256_N2: phase_bc<256, 32, 2>(pp, b, m0, smem); break;
-      case PK_BC384_N1: phase_bc<384, 16, 1>(pp, b, m0, smem); break;
-      case PK_BC384: phase_bc<384, 16, 0>(pp, b, m0, smem); break;
-      case PK_CONV_DEC3: phase_conv<48, 256, 384, 0, 384>(pp, b, m0, smem); break;
-      case PK_CONV_DEC2: phase_conv<64, 192, 256, 0, 256>(pp, b, m0, smem); break;
-      case PK_CONV_DEC1: phase_conv<128, 128, 192, 0, 192>(pp, b, m0, smem); break;
+      case PK_CONV_ENC1: if constexpr (PK_ON(PK_CONV_ENC1)) phase_conv<128, 128, 0, 0, 128>(pp, b, m0, smem); break;
+      case PK_CONV_ENC2A: if constexpr (PK_ON(PK_CONV_ENC2A)) phase_conv<64, 192, 0, 1, 128>(pp, b, m0, smem); break;
+      case PK_BC192: if constexpr (PK_ON(PK_BC192)) phase_bc<192, 64, 0>(pp, b, m0, smem); break;
+      case PK_CONV_ENC4: if constexpr (PK_ON(PK_CONV_ENC4)) phase_conv<48, 256, 0, 0, 192>(pp, b, m0, smem); break;
+      case PK_A256: if constexpr (PK_ON(PK_A256)) phase_a<256, 32>(pp, b, m0, smem); break;
+      case PK_BC256_N2: if constexpr (PK_ON(PK_BC256_N2)) phase_bc<256, 32, 2>(pp, b, m0, smem); break;
+      case PK_BC384_N1: if constexpr (PK_ON(PK_BC384_N1)) phase_bc<384, 16, 1>(pp, b, m0, smem); break;
+      case PK_BC384: if constexpr (PK_ON(PK_BC384)) phase_bc<384, 16, 0>(pp, b, m0, smem); break;
+      case PK_CONV_DEC3: if constexpr (PK_ON(PK_CONV_DEC3)) phase_conv<48, 256, 384, 0, 384>(pp, b, m0, smem); break;
+      case PK_CONV_DEC2: if constexpr (PK_ON(PK_CONV_DEC2)) phase_conv<64, 192, 256, 0, 256>(pp, b, m0, smem); break;
+      case PK_CONV_DEC1: if constexpr (PK_ON(PK_CONV_DEC1)) phase_conv<128, 128, 192, 0, 192>(pp, b, m0, smem); break;
       default: break;
     }
     {
