@@ -107,7 +107,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           PTRACE(0);
           if (ph > 0) {
             // L1 first: from here to the tile's loads this workgroup touches no activation (persist.h)
+#ifndef DHW_PERSIST_NOFENCE   // (timing experiment only: without the L1 invalidate the tile's loads may return stale rows)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
             const int t = gt - c.ns * plan->cum_tps[ph];
             const unsigned need = (unsigned)plan->ph[ph - 1].tps;
             const unsigned* cnt = c.done + (size_t)(ph - 1) * c.B + c.s0 + t / plan->ph[ph].tps;
