@@ -522,3 +522,47 @@ def test_bf16_mixed_precision_gradients_stay_close_and_training_still_learns(gol
         finals[prec] = (losses[0], losses[-1])
     print("loss first -> last after 40 updates:", finals)
     assert finals["bf16"][1] < 0.8 * finals["bf16"][0] and abs(finals["bf16"][1] - finals["fp32"][1]) < 0.15 * finals["fp32"][0]
+
+
+_SWITCH_WORKER = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from dhg_amd import spec, train, train_model as tm
+B, L, Lt = 4, 64, 10
+sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+model = tm.TrainModel(sd, num_layers=2, device=torch.device("cuda", 0))
+inp = spec.synthetic_inputs(B, L, Lt, S=14, seed=5, pad=3)
+g = torch.Generator().manual_seed(5)
+x = torch.from_numpy(inp["strokes"]); sig = torch.linspace(0.2, 0.9, B).reshape(B, 1)
+keep = (torch.rand(B, 14, 1280, generator=g) >= 0.3).float()
+score, pen = model.forward(x, torch.from_numpy(inp["text"]), sig, torch.from_numpy(inp["style"]), style_keep=keep)
+w1 = torch.randn(score.shape, generator=g).cuda(); w2 = torch.randn(pen.shape, generator=g).cuda()
+model.zero_grad(); model.backward(w1, w2)
+torch.cuda.synchronize()
+print(json.dumps({"launches": model.last_launches, "score": float(score.double().abs().sum()), "gnorm": float(model.flat_grad.double().norm()),
+                  "probe": model.flat_grad[::9973].double().cpu().tolist()}))
+"""
+
+
+def test_training_launch_switches_give_the_same_gradients(tmp_path):
+    """The round-4 launch mergers (a layer's weight + data gradient in one launch, grouped q / k / v, FiLM riding on the ConvBlock
+    GEMMs) and the 16-byte element-wise kernels only change WHICH launch computes a value: with each switch off the forward output and
+    the whole gradient vector agree to rounding (the 16-byte forms associate LayerNorm's sums differently: 1e-5 relative), and the
+    default issues fewer launches than every switched-off run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, env in (("default", {}), ("no_pair", {"DHW_SGEMM_PAIR": "0"}), ("no_group", {"DHW_SGEMM_GROUP": "0"}), ("no_vec4", {"DHW_TRAIN_VEC4": "0"}),
+                      ("no_rider", {"DHW_TRAIN_FILM_RIDER": "0"})):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_WORKER, root], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    ref = runs["default"]
+    for name, v in runs.items():
+        assert abs(v["score"] - ref["score"]) <= 1e-5 * abs(ref["score"]), name
+        assert abs(v["gnorm"] - ref["gnorm"]) <= 1e-5 * ref["gnorm"], name
+        assert np.allclose(v["probe"], ref["probe"], rtol=2e-4, atol=1e-6 * ref["gnorm"]), name
+    assert all(runs[k]["launches"] > ref["launches"] for k in ("no_pair", "no_group", "no_rider")), {k: v["launches"] for k, v in runs.items()}
