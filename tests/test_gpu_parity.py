@@ -110,6 +110,21 @@ def test_other_model_widths_match_reference_golden(golden_dir, prec, c2):
     assert np.abs(e_o.numpy() - g["eps_rand"]).max() < 2e-5 and np.abs(p_o.numpy() - g["pen_rand"]).max() < 2e-5
 
 
+def test_other_width_with_class_default_depth_matches_oracle():
+    """c = (128, 60, 256) with num_layers = 4 (the class default depth, model.py:66) — a width no fixture covers (head dims 20 and 15)
+    and ragged shapes — against the CPU oracle, which tests/test_oracle_golden.py pins to the reference at three other widths."""
+    c2, nl, B, L, Lt = 60, 4, 3, 72, 7
+    sd = {k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(nl, 128, c2, 256, seed=3).items()}
+    m = dhg_amd.DiffusionModel(nl, 128, c2, 256, precision="fp32", max_B=B, max_L=L, max_Lt=Lt).eval()
+    m.load_state_dict(sd, strict=True)
+    inp = spec.synthetic_inputs(B, L, Lt, seed=77, pad=2)
+    sg = torch.linspace(0.2, 0.9, B).reshape(B, 1)
+    eps, pen = fwd(m, inp, sg)
+    with torch.no_grad():
+        e_o, p_o = ref_cpu.forward(sd, torch.from_numpy(inp["strokes"]), torch.from_numpy(inp["text"]), sg, torch.from_numpy(inp["style"]))
+    assert np.abs(eps - e_o.numpy()).max() < TOL["fp32"]["eps"] and np.abs(pen - p_o.numpy()).max() < TOL["fp32"]["pen"]
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_every_block_matches_reference_taps(golden_dir, prec):
     g = np.load(os.path.join(golden_dir, "taps.npz"))
