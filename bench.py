@@ -424,10 +424,12 @@ def kernel_profile(model, one_step, ms_per_step):
     GPU time; `roofline["all_stroke_kernels"]` is the time-weighted figure over every fused stroke-side kernel.
 
     The profile pass launches eagerly (a replayed hipGraph has no per-kernel events): its event brackets include the gaps the
-    timed graph replay does not have, so their sum exceeds the timed step (r3: 21.9 vs 19.7 ms).  Every per-kernel time is
-    therefore SCALED by (timed ms per step) / (sum of event times) when that factor is below 1 — the per-kernel figures then
-    add up to the timed step and agree with the rocprofv3 summary of the same command (profiles/); the raw sum and the factor
-    are reported (`eager_event_sum_ms_per_step`, `event_time_scale`)."""
+    timed graph replay does not have, so their sum exceeds the timed step (r3: 21.9 vs 19.7 ms).  The excess is a roughly CONSTANT
+    cost per launch (event record + eager dispatch), not a share of the kernel's time, so it is removed as one constant per launch,
+    gap = (sum of event times - timed step) / launches — round 4 scaled every time by one factor instead, which under-timed the long
+    dominant kernel by ~5 % against rocprofv3 (33.4 vs 35.0 us) and overstated its roofline fraction.  The per-kernel figures then
+    add up to the timed step; they are DERIVED figures: the raw event mean of the dominant function is reported beside them
+    (`avg_launch_us_raw_event`) and the committed rocprofv3 summary of the same command (profiles/) is the cross-check."""
     import torch
     model.profile(True)
     one_step(10_000)
@@ -436,10 +438,17 @@ def kernel_profile(model, one_step, ms_per_step):
     model.profile(False)
     rows = [r for r in rows if r["launches"]]
     raw_total = sum(r["total_ms"] for r in rows)
-    scale = min(1.0, ms_per_step / raw_total) if raw_total > 0 else 1.0
+    n_launch = sum(r["launches"] for r in rows)
+    gap_ms = max(0.0, (raw_total - ms_per_step) / n_launch) if n_launch else 0.0
+    # (a kernel shorter than the gap keeps 10 % of its raw time rather than going negative; the remainder is spread again below)
+    for r in rows:
+        r["raw_ms"] = r["total_ms"]
+        r["total_ms"] = max(0.1 * r["total_ms"], r["total_ms"] - gap_ms * r["launches"])
+    total = sum(r["total_ms"] for r in rows)
+    scale = min(1.0, ms_per_step / total) if total > 0 and gap_ms > 0 else 1.0   # residual after the clamps (within a fraction of a percent of 1)
     for r in rows:
         r["total_ms"] *= scale
-    total = raw_total * scale
+    total *= scale
     table = []
     for r in sorted(rows, key=lambda r: -r["total_ms"]):
         us = r["total_ms"] * 1e3 / r["launches"]
@@ -449,8 +458,8 @@ def kernel_profile(model, one_step, ms_per_step):
                       "tflops": fl / us / 1e6 if us else 0.0, "gbs": by / us / 1e3 if us else 0.0})
     groups = {}
     for r in rows:
-        g = groups.setdefault(KERNEL_FUNCTION.get(r["label"], r["label"]), {"total_ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "labels": []})
-        for k in ("total_ms", "launches", "flops", "bytes"):
+        g = groups.setdefault(KERNEL_FUNCTION.get(r["label"], r["label"]), {"total_ms": 0.0, "raw_ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "labels": []})
+        for k in ("total_ms", "raw_ms", "launches", "flops", "bytes"):
             g[k] += r[k]
         g["labels"].append(r["label"])
     name, dom = max(((k, g) for k, g in groups.items() if g["flops"] > 0), key=lambda kg: kg[1]["total_ms"])
@@ -474,8 +483,10 @@ def kernel_profile(model, one_step, ms_per_step):
     roof.update({"traffic": traffic, "kernel": name, "labels": sorted(dom["labels"]), "avg_launch_us": us, "launches": dom["launches"],
                  "flops_per_launch": fl, "bytes_per_launch": by, "mfma_tflops": fl / us / 1e6, "hbm_gbs": by / us / 1e3,
                  "share_of_gpu_time": dom["total_ms"] / total, "sum_kernel_ms_per_step": total,
-                 "eager_event_sum_ms_per_step": raw_total, "event_time_scale": scale,
-                 "timing": "HIP events around eager launches, scaled by event_time_scale so that the per-kernel times add up to the timed (graph replay) step",
+                 "eager_event_sum_ms_per_step": raw_total, "eager_gap_us_per_launch": gap_ms * 1e3, "launches_per_step": n_launch, "event_time_scale": scale,
+                 "avg_launch_us_raw_event": dom["raw_ms"] * 1e3 / dom["launches"],
+                 "timing": "HIP events around eager launches minus one constant per launch (eager_gap_us_per_launch = (event sum - timed graph-replay step) / launches), "
+                           "so that the per-kernel times add up to the timed step; derived — cross-check: profiles/ rocprofv3 kernel stats of the same command",
                  "by_function": {k: {"share": g["total_ms"] / total, "avg_us": g["total_ms"] * 1e3 / g["launches"], "launches": g["launches"],
                                      "mfma_frac": g["flops"] / (g["total_ms"] * 1e9) / PEAK_BF16_TFLOPS if g["total_ms"] else 0.0}
                                  for k, g in sorted(groups.items(), key=lambda kg: -kg[1]["total_ms"]) if g["flops"] > 0},
@@ -488,7 +499,7 @@ def kernel_profile(model, one_step, ms_per_step):
 # csrc files that are NOT part of the sampling path (training step, StyleExtractor): left out of the sampler's source hash.
 # Every other file under csrc/ is hashed, so a new kernel header can never be silently missing
 # (tests/test_host_cpu.py::test_kernel_source_hash_covers_csrc keeps the two lists exhaustive).
-NON_SAMPLER_SOURCES = {"train.hip", "dhw_train_api.cpp", "style.hip", "dhw_style_api.cpp"}
+NON_SAMPLER_SOURCES = {"train.hip", "dhw_train_api.cpp", "style.hip", "dhw_style_api.cpp", "abi_guard.h"}
 SAMPLER_SOURCES = {"convblock.hip", "convblock_core.h", "enclayer.hip", "enc_a_core.h", "enc_bc_core.h", "persist.hip", "persist.h", "gemm.hip", "gemm_core.h",
                    "attn.hip", "attn_core.h", "misc.hip", "textside.hip", "epilogue.h", "heads_core.h", "dhw_common.h", "dhw_kernels.h", "xcd_swizzle.h",
                    "dhw_api.cpp"}

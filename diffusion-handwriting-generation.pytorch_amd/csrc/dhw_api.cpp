@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/dhw.h"
+#include "abi_guard.h"
 #include "xcd_swizzle.h"
 #include "../../include/dhw_debug.h"
 #include "dhw_kernels.h"
@@ -28,7 +29,7 @@ namespace {
 constexpr int SIG = 32, SIG_HID = 2048, VOCAB = 73, STYLE_CH = 256;
 constexpr int SLACK_ROWS = 64;   // every activation buffer is over-allocated so tile over-reads stay in bounds
 
-std::string g_err;
+ErrBuf g_err;   // errors without a handle (dhw_create, dhw_schedule); a fixed buffer: recording an error never throws
 
 struct KeySpec { std::string key; std::vector<int64_t> shape; };
 
@@ -123,11 +124,38 @@ struct ProfRec { int label; hipEvent_t a, b; double flops, bytes; };
 struct ProfAgg { std::string label; double ms = 0, flops = 0, bytes = 0; int64_t n = 0; };
 
 struct Tap { void* p; int rows; int cols; bool f32; };
+// dhw_debug_read's view of the last call: one slot per named activation, names resolved ONCE at dhw_create (build_names);
+// a launch only touches slot ids.  (Round 4 kept a std::map<std::string, Tap> filled with names concatenated at every launch.)
+struct TapSlot { std::string name; Tap t{}; bool set = false; };
+
+// ConvBlocks and EncoderLayers by index: nothing on the launch path is looked up by name.
+enum { CB_ENC1, CB_ENC2, CB_ENC4, CB_DEC3, CB_DEC2, CB_DEC1, CB_N };
+constexpr const char* kConvName[CB_N] = {"enc1", "enc2", "enc4", "dec3", "dec2", "dec1"};
+// EncoderLayer li: 0 = enc3, 1 = enc5, 2 + i = att_layers.i
+enum { TAP_SIGMA_FFN, TAP_INPUT_DENSE, TAP_TS, TAP_TS_STYLE, TAP_TS_T2, TAP_ATT_DENSE, TAP_UP3, TAP_UP2, TAP_UP1, TAP_CONV0 };
+inline int tap_conv(int id) { return TAP_CONV0 + id; }
+inline int tap_el(int li, int which) { return TAP_CONV0 + CB_N + 3 * li + which; }   // which: 0 = layer output, 1 = .x2, 2 = .x3
 
 // One full activation workspace.  dhw_sample splits a prompt batch into independent sub-batches, each
 // with its own workspace on its own (captured) stream, so several small kernels are in flight at once.
+// Every buffer is a NAMED POINTER set by alloc_workspace / ensure_plane (dhw_create, or the first dhw_sample of a longer
+// schedule): a buffer the launch sequence needs and the allocation code forgot is reported by need() as DHW_ERR_INTERNAL
+// before anything is launched.  (Round 4: a std::map<std::string, void*> looked up with .at(name + ".k1") at every launch;
+// a renamed buffer threw std::out_of_range through dhw_forward and aborted the host process.)
+struct ConvBufs { void *h1 = nullptr, *h2 = nullptr, *out = nullptr; };
+struct TextBufs { void *s1 = nullptr, *k8 = nullptr, *vt8 = nullptr, *t1 = nullptr, *q8 = nullptr, *a8 = nullptr, *t2 = nullptr, *tf_h = nullptr, *text_out = nullptr; };
+struct EncTextBufs { void *tl = nullptr, *k1 = nullptr, *vt1 = nullptr; };
+struct EncBufs {
+  EncTextBufs t, tT;   // the layer's text-side projections: per call, and the all-steps plane
+  void *q1 = nullptr, *a1 = nullptr, *x2 = nullptr, *qk2 = nullptr, *vt2 = nullptr, *a2 = nullptr, *x3 = nullptr, *f = nullptr, *out = nullptr;
+};
 struct Workspace {
-  std::map<std::string, void*> buf;
+  void *sty_in = nullptr, *sty_h = nullptr, *sty_n = nullptr, *t_n = nullptr;
+  TextBufs ts, tsT;    // sigma-dependent text side: per call, and the all-steps plane (".T")
+  void *x0 = nullptr, *enc1_pool = nullptr, *enc3_pool = nullptr, *enc5_pool = nullptr, *att_dense = nullptr;
+  void* xd[3] = {nullptr, nullptr, nullptr};   // decoder inputs xd3, xd2, xd1 (DHW_FUSE_UP=0 only)
+  ConvBufs cb[CB_N];
+  std::vector<EncBufs> el;
   float* d_xt = nullptr;   // fp32 sampler state [B*L, 2]
   long cap_B = 0;          // prompts this workspace was sized for
   long plane_cap = 0;      // (steps x prompts) the all-steps text plane (".T" buffers) is sized for
@@ -159,7 +187,8 @@ struct dhw_handle {
   int device = 0;
   int prec = 0;
   size_t es = 2;
-  std::string err;
+  ErrBuf err;
+  bool lookup_fail = false;   // a weight / FiLM name the packing code asked for does not exist (W, film_offset): finalize fails
   std::vector<KeySpec> spec;
   std::map<std::string, int> key_index;
   std::vector<std::vector<float>> host_w;
@@ -199,7 +228,8 @@ struct dhw_handle {
   int nstreams = 1;
   int nstreams_alloc = 1;
   hipStream_t sub_streams[MAX_STREAMS] = {};
-  std::map<std::string, Tap> taps;
+  std::vector<TapSlot> taps;            // indexed by tap id (TAP_*, tap_conv, tap_el)
+  std::vector<std::string> el_name;     // "enc3", "enc5", "att_layers.i"
   int lpadT = 0, lpadS = 0, lpadX[3] = {0, 0, 0};
 
   // profiling
@@ -249,16 +279,18 @@ struct dhw_handle {
 
 namespace {
 
-int fail(dhw_handle* h, int code, const char* fmt, ...) {
-  char tmp[512];
+int fail(dhw_handle* h, int code, const char* fmt, ...) noexcept {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  g_err.vsetf(fmt, ap);
   va_end(ap);
-  if (h) h->err = tmp;
-  g_err = tmp;
+  if (h) h->err.set(g_err.c_str());
   return code;
 }
+
+// The body of every extern "C" entry point runs inside this: no exception leaves the library (abi_guard.h).
+#define DHW_GUARD(h, fn, R, ...) \
+  return abi_guard<R>(fn, [&](const char* f_, const char* w_) { return fail((h), DHW_ERR_INTERNAL, "%s: internal error: %s", f_, w_); }, [&]() -> R __VA_ARGS__)
 
 #define HIPCK(h, call)                                                                                  \
   do {                                                                                                  \
@@ -273,9 +305,31 @@ int dev_alloc(dhw_handle* h, void** p, size_t bytes, bool zero = true) {
   return 0;
 }
 
-const std::vector<float>& W(dhw_handle* h, const std::string& key) { return (h->padded ? h->phys_w : h->host_w)[h->key_index.at(key)]; }
+// A weight by state_dict key (finalize-time only).  The packing code names the same keys build_spec declares, so a miss is a
+// programming error: it is recorded (dhw_finalize then returns DHW_ERR_INTERNAL) and an empty tensor is returned, which the
+// upload helpers reject by size — nothing throws.
+const std::vector<float>& W(dhw_handle* h, const std::string& key) {
+  static const std::vector<float> none;
+  auto it = h->key_index.find(key);
+  if (it == h->key_index.end()) {
+    if (!h->lookup_fail) fail(h, DHW_ERR_INTERNAL, "internal: the packing code asked for an unknown weight '%s'", key.c_str());
+    h->lookup_fail = true;
+    return none;
+  }
+  return (h->padded ? h->phys_w : h->host_w)[it->second];
+}
+int film_offset(dhw_handle* h, const std::string& name) {
+  auto it = h->film_off.find(name);
+  if (it == h->film_off.end()) {
+    if (!h->lookup_fail) fail(h, DHW_ERR_INTERNAL, "internal: no FiLM layer named '%s'", name.c_str());
+    h->lookup_fail = true;
+    return 0;
+  }
+  return it->second;
+}
 
 int upload_f32(dhw_handle* h, const std::vector<float>& v, float** out) {
+  if (h->lookup_fail) return DHW_ERR_INTERNAL;
   int rc = dev_alloc(h, (void**)out, v.size() * 4, false);
   if (rc) return rc;
   HIPCK(h, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
@@ -285,7 +339,8 @@ int upload_f32(dhw_handle* h, const std::vector<float>& v, float** out) {
 // Pack a row-major weight matrix Wf[N][K] into MFMA-fragment order
 // [N/16][K/32][64 lanes][8]: lane l holds Wf[nt*16 + (l&15)][kc*32 + 8*(l>>4) + j].
 int upload_packed(dhw_handle* h, const std::vector<float>& wf, int N, int K, void** out) {
-  if (N % 16 || K % 32 || (size_t)N * K != wf.size()) return fail(h, DHW_ERR_ARG, "pack: bad shape %d x %d", N, K);
+  if (h->lookup_fail) return DHW_ERR_INTERNAL;
+  if (N % 16 || K % 32 || (size_t)N * K != wf.size()) return fail(h, DHW_ERR_INTERNAL, "pack: bad shape %d x %d", N, K);
   const size_t n = (size_t)N * K;
   std::vector<float> pk(n);
   size_t o = 0;
@@ -433,9 +488,9 @@ int pack_convblock(dhw_handle* h, const std::string& n, int cin, int cout, ConvB
   if ((rc = upload_f32(h, W(h, n + ".conv2.bias"), &cb.b_c2))) return rc;
   if ((rc = upload_f32(h, W(h, n + ".fc.bias"), &cb.b_fc))) return rc;
   if ((rc = upload_f32(h, W(h, n + ".conv_skip.bias"), &cb.b_skip))) return rc;
-  cb.f1 = h->film_off.at(n + ".affine1");
-  cb.f2 = h->film_off.at(n + ".affine2");
-  cb.f3 = h->film_off.at(n + ".affine3");
+  cb.f1 = film_offset(h, n + ".affine1");
+  cb.f2 = film_offset(h, n + ".affine2");
+  cb.f3 = film_offset(h, n + ".affine3");
   return 0;
 }
 
@@ -473,23 +528,23 @@ int pack_enclayer(dhw_handle* h, const std::string& n, int d, int heads, float p
   if ((rc = upload_f32(h, pe_times_w(pe_t, h->dims.max_Lt + SLACK_ROWS, d, wk1, d), &e.pb_k1))) return rc;
   if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, wq1, d), &e.pb_q1))) return rc;
   if ((rc = upload_f32(h, pe_times_w(pe_x, max_lk + SLACK_ROWS, d, vcat({&wq2, &wk2}), 2 * d), &e.pb_qk2))) return rc;
-  e.f0 = h->film_off.at(n + ".affine0");
-  e.f1 = h->film_off.at(n + ".affine1");
-  e.f2 = h->film_off.at(n + ".affine2");
-  e.f3 = h->film_off.at(n + ".affine3");
+  e.f0 = film_offset(h, n + ".affine0");
+  e.f1 = film_offset(h, n + ".affine1");
+  e.f2 = film_offset(h, n + ".affine2");
+  e.f3 = film_offset(h, n + ".affine3");
   return 0;
 }
 
-int act_alloc(dhw_handle* h, Workspace& w, const std::string& name, long rows, int cols, bool f32 = false) {
-  void* p;
+int act_alloc(dhw_handle* h, void** slot, long rows, int cols, bool f32 = false) {
   const size_t bytes = (size_t)(rows + SLACK_ROWS) * cols * (f32 ? 4 : h->es);
-  int rc = dev_alloc(h, &p, bytes, true);
-  if (rc) return rc;
-  w.buf[name] = p;
-  return 0;
+  return dev_alloc(h, slot, bytes, true);
 }
 
 int pad32(int x) { return ((x + 31) / 32) * 32; }
+
+// width of EncoderLayer li (0 = enc3 at c2, 1 = enc5 at c3, the bottleneck layers at 2 c2) and its stroke rows at length L
+int el_width(const dhw_dims& d, int li) { return li == 0 ? d.c2 : li == 1 ? d.c3 : 2 * d.c2; }
+long el_rows(long L, int li) { return li == 0 ? L / 2 : li == 1 ? L / 4 : L / 8; }
 
 int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
   w.cap_B = B;
@@ -497,43 +552,42 @@ int alloc_workspace(dhw_handle* h, Workspace& w, long B) {
   const long L = d.max_L, Lt = d.max_Lt, S5 = d.S * 5;
   const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
   int rc;
-#define AA(name, rows, cols) if ((rc = act_alloc(h, w, name, rows, cols))) return rc
-  AA("sty_in", B * S5, STYLE_CH); AA("sty_h", B * S5, 4 * c2); AA("sty_n", B * S5, dt); AA("s1", B * S5, dt);
-  AA("k8", B * S5, dt);
-  AA("t_n", B * Lt, dt); AA("t1", B * Lt, dt); AA("q8", B * Lt, dt); AA("a8", B * Lt, dt); AA("t2", B * Lt, dt);
-  AA("tf_h", B * Lt, 2 * dt); AA("text_out", B * Lt, dt);
+#define AA(slot, rows, cols) if ((rc = act_alloc(h, &(slot), rows, cols))) return rc
+  AA(w.sty_in, B * S5, STYLE_CH); AA(w.sty_h, B * S5, 4 * c2); AA(w.sty_n, B * S5, dt); AA(w.ts.s1, B * S5, dt);
+  AA(w.ts.k8, B * S5, dt);
+  AA(w.t_n, B * Lt, dt); AA(w.ts.t1, B * Lt, dt); AA(w.ts.q8, B * Lt, dt); AA(w.ts.a8, B * Lt, dt); AA(w.ts.t2, B * Lt, dt);
+  AA(w.ts.tf_h, B * Lt, 2 * dt); AA(w.ts.text_out, B * Lt, dt);
   h->lpadS = pad32((int)S5);
   h->lpadT = pad32((int)Lt);
-  AA("vt8", B * dt, h->lpadS);
-  AA("x0", B * L, c1);
-  struct CB { const char* n; long rows; int cin, cout; };
-  const CB cbs[6] = {{"enc1", L, c1, c1}, {"enc2", L / 2, c1, c2}, {"enc4", L / 4, c2, c3},
-                     {"dec3", L / 4, dt, c3}, {"dec2", L / 2, c3, c2}, {"dec1", L, c2, c1}};
-  for (const CB& c : cbs) {
-    AA(std::string(c.n) + ".h1", B * c.rows, c.cout / 2);
-    AA(std::string(c.n) + ".h2", B * c.rows, c.cout);
-    if (std::string(c.n) == "dec1") { if ((rc = act_alloc(h, w, "dec1", B * c.rows, c.cout, true))) return rc; }
-    else AA(c.n, B * c.rows, c.cout);
+  AA(w.ts.vt8, B * dt, h->lpadS);
+  AA(w.x0, B * L, c1);
+  struct CB { long rows; int cout; };
+  const CB cbs[CB_N] = {{L, c1}, {L / 2, c2}, {L / 4, c3}, {L / 4, c3}, {L / 2, c2}, {L, c1}};
+  for (int i = 0; i < CB_N; ++i) {
+    const CB& c = cbs[i];
+    AA(w.cb[i].h1, B * c.rows, c.cout / 2);
+    AA(w.cb[i].h2, B * c.rows, c.cout);
+    if (i == CB_DEC1) { if ((rc = act_alloc(h, &w.cb[i].out, B * c.rows, c.cout, true))) return rc; }   // dec1's output feeds the heads in fp32
+    else AA(w.cb[i].out, B * c.rows, c.cout);
   }
-  AA("enc1.pool", B * L / 2, c1);
-  struct EL { std::string n; long rows; int dm; };
-  std::vector<EL> els = {{"enc3", L / 2, c2}, {"enc5", L / 4, c3}};
-  for (int i = 0; i < d.num_layers; ++i) els.push_back({"att_layers." + std::to_string(i), L / 8, dt});
+  AA(w.enc1_pool, B * L / 2, c1);
   h->lpadX[0] = pad32((int)(L / 2));
   h->lpadX[1] = pad32((int)(L / 4));
   h->lpadX[2] = pad32((int)(L / 8));
-  for (size_t i = 0; i < els.size(); ++i) {
-    const EL& e = els[i];
-    const int lp = h->lpadX[i < 2 ? i : 2];
-    AA(e.n + ".tl", B * Lt, e.dm); AA(e.n + ".k1", B * Lt, e.dm); AA(e.n + ".vt1", B * e.dm, h->lpadT);
-    AA(e.n + ".q1", B * e.rows, e.dm); AA(e.n + ".a1", B * e.rows, e.dm); AA(e.n + ".x2", B * e.rows, e.dm);
+  w.el.assign(2 + d.num_layers, EncBufs{});
+  for (size_t i = 0; i < w.el.size(); ++i) {
+    EncBufs& e = w.el[i];
+    const int dm = el_width(d, (int)i), lp = h->lpadX[i < 2 ? i : 2];
+    const long rows = el_rows(L, (int)i);
+    AA(e.t.tl, B * Lt, dm); AA(e.t.k1, B * Lt, dm); AA(e.t.vt1, B * dm, h->lpadT);
+    AA(e.q1, B * rows, dm); AA(e.a1, B * rows, dm); AA(e.x2, B * rows, dm);
     // (qk2: the bf16 fused kernels keep [q2 | k2 | v2] rows; the other paths use 2 dm columns of it and the transposed vt2)
-    AA(e.n + ".qk2", B * e.rows, 3 * e.dm); AA(e.n + ".vt2", B * e.dm, lp); AA(e.n + ".a2", B * e.rows, e.dm);
-    AA(e.n + ".x3", B * e.rows, e.dm); AA(e.n + ".f", B * e.rows, 2 * e.dm); AA(e.n, B * e.rows, e.dm);
+    AA(e.qk2, B * rows, 3 * dm); AA(e.vt2, B * dm, lp); AA(e.a2, B * rows, dm);
+    AA(e.x3, B * rows, dm); AA(e.f, B * rows, 2 * dm); AA(e.out, B * rows, dm);
   }
-  AA("enc3.pool", B * L / 4, c2); AA("enc5.pool", B * L / 8, c3);
-  AA("att_dense", B * L / 8, dt);
-  AA("xd3", B * L / 4, dt); AA("xd2", B * L / 2, c3); AA("xd1", B * L, c2);
+  AA(w.enc3_pool, B * L / 4, c2); AA(w.enc5_pool, B * L / 8, c3);
+  AA(w.att_dense, B * L / 8, dt);
+  AA(w.xd[0], B * L / 4, dt); AA(w.xd[1], B * L / 2, c3); AA(w.xd[2], B * L, c2);
 #undef AA
   if ((rc = dev_alloc(h, (void**)&w.d_xt, (size_t)(B * L + SLACK_ROWS) * 2 * 4))) return rc;
   return 0;
@@ -544,22 +598,21 @@ int ensure_plane(dhw_handle* h, Workspace& w, long steps, long B) {
   if (steps * B <= w.plane_cap) return 0;
   const dhw_dims& d = h->dims;
   const long n = steps * B, Lt = d.max_Lt, S5 = d.S * 5;
-  const int c2 = d.c2, c3 = d.c3, dt = 2 * c2;
+  const int dt = 2 * d.c2;
   int rc;
-#define AA(name, rows, cols) if ((rc = act_alloc(h, w, name, rows, cols))) return rc
-  // with the fused text-side kernels (every call of this handle qualifies) only text_out and the layers' K / V^T exist
+#define AA(slot, rows, cols) if ((rc = act_alloc(h, &(slot), rows, cols))) return rc
+  // with the fused text-side kernels (every call of this handle qualifies) only text_out and the layers' K / V exist
   const bool fused = h->fuse && h->fuse_text && textside_supported(h->prec, (int)Lt, (int)S5, dt);
   if (!fused) {
-    AA("s1.T", n * S5, dt); AA("k8.T", n * S5, dt); AA("vt8.T", n * dt, h->lpadS);
-    AA("t1.T", n * Lt, dt); AA("q8.T", n * Lt, dt); AA("a8.T", n * Lt, dt); AA("t2.T", n * Lt, dt);
-    AA("tf_h.T", n * Lt, 2 * dt);
+    AA(w.tsT.s1, n * S5, dt); AA(w.tsT.k8, n * S5, dt); AA(w.tsT.vt8, n * dt, h->lpadS);
+    AA(w.tsT.t1, n * Lt, dt); AA(w.tsT.q8, n * Lt, dt); AA(w.tsT.a8, n * Lt, dt); AA(w.tsT.t2, n * Lt, dt);
+    AA(w.tsT.tf_h, n * Lt, 2 * dt);
   }
-  AA("text_out.T", n * Lt, dt);
-  std::vector<std::pair<std::string, int>> els = {{"enc3", c2}, {"enc5", c3}};
-  for (int i = 0; i < d.num_layers; ++i) els.push_back({"att_layers." + std::to_string(i), dt});
-  for (auto& e : els) {
-    if (!fused) AA(e.first + ".tl.T", n * Lt, e.second);
-    AA(e.first + ".k1.T", n * Lt, e.second); AA(e.first + ".vt1.T", n * e.second, h->lpadT);
+  AA(w.tsT.text_out, n * Lt, dt);
+  for (size_t i = 0; i < w.el.size(); ++i) {
+    const int dm = el_width(d, (int)i);
+    if (!fused) AA(w.el[i].tT.tl, n * Lt, dm);
+    AA(w.el[i].tT.k1, n * Lt, dm); AA(w.el[i].tT.vt1, n * dm, h->lpadT);
   }
 #undef AA
   w.plane_cap = n;   // (a grown plane leaks the smaller one until destroy)
@@ -626,7 +679,7 @@ struct Ctx {
   int err = 0;
   int film_div = 1;    // samples per FiLM row
   int in_B = 0;        // batch of the sigma-independent inputs (0 = B); the text plane replicates them over steps
-  std::string sfx;     // suffix of the text-side output buffers: "" (per call) or ".T" (all-steps plane)
+  bool planeT = false; // the text side writes the all-steps plane (".T" buffers) instead of the per-call ones
   const HeadsParams* fhp = nullptr;   // sampling loop: dec1 evaluates the heads + scheduler step itself
   bool fuse_input = false;  // enc1 evaluates input_dense while staging (sampling loop); forward() keeps the tap
   bool use_plane = false;   // stroke path reads the text K/V of step `plane_step` from the plane
@@ -651,7 +704,19 @@ void rec_phase(Ctx& c, int kind, int L, const ConvBlockParams* cb, const EncLaye
   c.rec->push_back(ph);
 }
 
-void* BUF(const Ctx& c, const std::string& n) { return c.ws->buf.at(n); }
+// A workspace pointer the launch sequence is about to hand to a kernel.  All of them are set when the workspace is allocated
+// (alloc_workspace at dhw_create, ensure_plane); one that is still null here is a bug in that code: it becomes a status
+// (every launch helper checks c.err first) — not a throw across the ABI and not a null dereference on the device.
+void* need(Ctx& c, void* p, const char* what) {
+  if (!p && !c.err) c.err = fail(c.h, DHW_ERR_INTERNAL, "internal: workspace buffer '%s' was never allocated", what);
+  return p;
+}
+#define WS(c, field) need((c), (c).ws->field, #field)
+#define TS(c, field) need((c), ((c).planeT ? (c).ws->tsT : (c).ws->ts).field, (c).planeT ? #field ".T" : #field)          /* sigma-dependent text side */
+#define CBB(c, id, field) need((c), (c).ws->cb[id].field, #field)                                                        /* ConvBlock id */
+#define ELB(c, li, field) need((c), (c).ws->el[li].field, #field)                                                        /* EncoderLayer li */
+#define ELT(c, li, field) need((c), ((c).planeT ? (c).ws->el[li].tT : (c).ws->el[li].t).field, (c).planeT ? #field ".T" : #field)   /* its text projections, as the text side writes them */
+#define ELK(c, li, field) need((c), ((c).use_plane ? (c).ws->el[li].tT : (c).ws->el[li].t).field, (c).use_plane ? #field ".T" : #field)   /* ... as the stroke side reads them */
 
 GemmParams gp_base(const Ctx& c, int L, int N) {
   GemmParams p{};
@@ -724,8 +789,13 @@ void run_attn(Ctx& c, const char* label, const AttnParams& p) {
     }                                                                                              \
   } while (0)
 
-void tap(Ctx& c, const std::string& name, const std::string& bufname, int rows, int cols, bool f32 = false) {
-  c.h->taps[name] = Tap{BUF(c, bufname), rows, cols, f32};
+void tap(Ctx& c, int id, void* p, int rows, int cols, bool f32 = false) {
+  TapSlot& s = c.h->taps[id];
+  s.t = Tap{p, rows, cols, f32};
+  s.set = true;
+}
+void taps_clear(dhw_handle* h) {
+  for (TapSlot& s : h->taps) s.set = false;
 }
 
 // decoder input produced inside the block: Upsample(low) + skip_conv(hskip)  (model.py:169-175)
@@ -734,10 +804,11 @@ struct UpIn { const void* hskip; const void* w; const float* b; int cin; const v
 // cnn.py:64-87 as one fused launch (or three fused GEMM launches)
 // chain: the EncoderLayer half the block's workgroups continue with (EncChain mode 1), or null; *chained reports
 // whether the launch took it
-void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
+void conv_block(Ctx& c, int id, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
                 void* pool, const float* strokes = nullptr, const UpIn* up = nullptr, const EncChain* chain = nullptr,
                 bool* chained = nullptr) {
   dhw_handle* h = c.h;
+  const char* n = kConvName[id];
   if (h->fuse) {
     ConvBlockParams q{};
     q.strokes = strokes; q.in_w = h->in_w; q.in_b = h->in_b;
@@ -748,7 +819,7 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot;
     q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
     q.out = out; q.out_f32 = out_f32; q.pool = pool;
-    if (c.fhp && n == "dec1") {
+    if (c.fhp && id == CB_DEC1) {
       q.fuse_heads = 1;
       q.hp = *c.fhp;
       q.hp.w_out = h->out_w; q.hp.b_out = h->out_b; q.hp.w_pen = h->pen_w; q.hp.b_pen = h->pen_b;
@@ -760,12 +831,12 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
       const bool ch = chain && chain->mode == 1 && convblock_chain_supported(h->prec, q, *chain);
       if (chained) *chained = ch;
       int kind = -1;
-      if (n == "enc1" && strokes && !up) kind = PK_CONV_ENC1;
-      else if (n == "enc2" && ch && !up && !strokes) kind = PK_CONV_ENC2A;
-      else if (n == "enc4" && !(chain && chain->mode) && !up && !strokes) kind = PK_CONV_ENC4;
-      else if (n == "dec3" && up) kind = PK_CONV_DEC3;
-      else if (n == "dec2" && up) kind = PK_CONV_DEC2;
-      else if (n == "dec1" && up && q.fuse_heads) kind = PK_CONV_DEC1;
+      if (id == CB_ENC1 && strokes && !up) kind = PK_CONV_ENC1;
+      else if (id == CB_ENC2 && ch && !up && !strokes) kind = PK_CONV_ENC2A;
+      else if (id == CB_ENC4 && !(chain && chain->mode) && !up && !strokes) kind = PK_CONV_ENC4;
+      else if (id == CB_DEC3 && up) kind = PK_CONV_DEC3;
+      else if (id == CB_DEC2 && up) kind = PK_CONV_DEC2;
+      else if (id == CB_DEC1 && up && q.fuse_heads) kind = PK_CONV_DEC1;
       if (kind < 0 || h->prec != PREC_BF16 || (L & 1)) { c.rec_fail = true; return; }
       rec_phase(c, kind, c.L, &q, nullptr, ch ? chain : nullptr);
       return;
@@ -781,9 +852,9 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
                rows * ((up ? up->cin + 0.5 * w.cin : w.cin) * h->es + w.cout * (out_f32 ? 4.0 : (double)h->es) * (pool ? 1.5 : 1.0)) +
                    (4.5 * w.cin * w.cout + 2.5 * w.cout * w.cout + upf) * h->es + chb);
       hipError_t e = ch ? launch_convblock_chain(h->prec, q, *chain, c.st) : launch_convblock(h->prec, q, c.st);
-      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "convblock %s: %s", n.c_str(), hipGetErrorString(e));
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "convblock %s: %s", n, hipGetErrorString(e));
     }
-    tap(c, n, n, L, w.cout, out_f32);
+    tap(c, tap_conv(id), out, L, w.cout, out_f32);
     return;
   }
   if (c.rec) { c.rec_fail = true; return; }
@@ -793,22 +864,22 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     p.bias0 = w.b_c1;
     set_film(c, p, w.f1, 1);
     p.silu_out = 1;
-    p.out = BUF(c, n + ".h1");
+    p.out = CBB(c, id, h1);
     run_gemm(c, "convblock.conv1", p);
   }
   {  // h2 = SiLU(FiLM2(conv2(h1)))
     GemmParams p = gp_base(c, L, w.cout);
-    p.seg[0] = GemmSeg{BUF(c, n + ".h1"), w.w_c2, w.cout / 2, 3, 0};
+    p.seg[0] = GemmSeg{CBB(c, id, h1), w.w_c2, w.cout / 2, 3, 0};
     p.bias0 = w.b_c2;
     set_film(c, p, w.f2, 1);
     p.silu_out = 1;
-    p.out = BUF(c, n + ".h2");
+    p.out = CBB(c, id, h2);
     run_gemm(c, "convblock.conv2", p);
   }
   {  // out = FiLM3(fc(h2)) + conv_skip(x)
     GemmParams p = gp_base(c, L, w.cout);
     p.nseg = 2;
-    p.seg[0] = GemmSeg{BUF(c, n + ".h2"), w.w_fc, w.cout, 1, 0};
+    p.seg[0] = GemmSeg{CBB(c, id, h2), w.w_fc, w.cout, 1, 0};
     p.seg[1] = GemmSeg{x, w.w_skip, w.cin, 3, 0};
     p.bias0 = w.b_fc;
     p.bias1 = w.b_skip;
@@ -818,23 +889,23 @@ void conv_block(Ctx& c, const std::string& n, const ConvBlockW& w, const void* x
     p.pool = pool;
     run_gemm(c, "convblock.fc_skip", p);
   }
-  tap(c, n, n, L, w.cout, out_f32);
+  tap(c, tap_conv(id), out, L, w.cout, out_f32);
 }
 
 // the layer's text values are kept as rows [B*Lt, d] (fused bf16 EncoderLayer kernels) instead of transposed [B][d][lpadT]
 bool v_rows(const dhw_handle* h, const EncLayerW& w) { return h->fuse && h->prec == PREC_BF16 && enclayer_supported(h->prec, w.d, w.heads); }
 
 // model.py:37-58.  The text-side projections (tl, k1, vt1) are produced by enc_layer_text.
-void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
+void enc_layer_text(Ctx& c, int li, const EncLayerW& w) {
   dhw_handle* h = c.h;
   const int dt = 2 * h->dims.c2;
   {  // tl = FiLM0(LN(text_dense(SiLU(text))))
     GemmParams p = gp_text(c, c.Lt, w.d);
-    p.seg[0] = GemmSeg{BUF(c, "text_out" + c.sfx), w.w_td, dt, 1, 1};
+    p.seg[0] = GemmSeg{TS(c, text_out), w.w_td, dt, 1, 1};
     p.bias0 = w.b_td;
     p.ln = 1;
     set_film(c, p, w.f0, 1);
-    p.out = BUF(c, n + ".tl" + c.sfx);
+    p.out = ELT(c, li, tl);
     run_gemm(c, "enc.text_dense", p);
   }
   if (v_rows(h, w)) {
@@ -842,34 +913,34 @@ void enc_layer_text(Ctx& c, const std::string& n, const EncLayerW& w) {
     // stacked [2d x d] weight's halves (this generic text path only runs with DHW_FUSE_TEXT=0 / unsupported text shapes)
     for (int half = 0; half < 2; ++half) {
       GemmParams p = gp_base(c, c.Lt, w.d);
-      p.seg[0] = GemmSeg{BUF(c, n + ".tl" + c.sfx), (const char*)w.w_kv1 + (size_t)half * w.d * w.d * h->es, w.d, 1, 0};
+      p.seg[0] = GemmSeg{ELT(c, li, tl), (const char*)w.w_kv1 + (size_t)half * w.d * w.d * h->es, w.d, 1, 0};
       p.bias0 = w.b_kv1 + half * w.d;
       if (half == 0) { p.posb = w.pb_k1; p.posb_cols = w.d; }
-      p.out = BUF(c, n + (half ? ".vt1" : ".k1") + c.sfx);
+      p.out = half ? ELT(c, li, vt1) : ELT(c, li, k1);
       run_gemm(c, half ? "enc.v_text" : "enc.k_text", p);
     }
   } else {  // k1 = Wk(tl + PE), v1 = Wv(tl)   (values carry no PE: model.py:46)
     GemmParams p = gp_base(c, c.Lt, 2 * w.d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".tl" + c.sfx), w.w_kv1, w.d, 1, 0};
+    p.seg[0] = GemmSeg{ELT(c, li, tl), w.w_kv1, w.d, 1, 0};
     p.bias0 = w.b_kv1;
     p.posb = w.pb_k1;
     p.posb_cols = w.d;
     p.n_store = w.d;
-    p.out = BUF(c, n + ".k1" + c.sfx);
-    p.vt = BUF(c, n + ".vt1" + c.sfx);
+    p.out = ELT(c, li, k1);
+    p.vt = ELT(c, li, vt1);
     p.vt_lpad = h->lpadT;
     run_gemm(c, "enc.kv_text", p);
   }
 }
 
 // parameters of the fused EncoderLayer kernels for layer n (x may be null when the tile is handed over in LDS)
-EncLayerParams enc_params(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
+EncLayerParams enc_params(Ctx& c, int li, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
                           void* pool) {
   dhw_handle* h = c.h;
   const int d = w.d;
   // text keys/values of this layer: per-call buffers, or step `plane_step` of the all-steps plane
-  const char* k1p = (const char*)BUF(c, n + (c.use_plane ? ".k1.T" : ".k1"));
-  const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
+  const char* k1p = (const char*)ELK(c, li, k1);
+  const char* vt1p = (const char*)ELK(c, li, vt1);
   if (c.use_plane) {
     k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
     vt1p += (size_t)c.plane_step * c.B * (v_rows(h, w) ? c.Lt : h->lpadT) * d * h->es;
@@ -882,25 +953,25 @@ EncLayerParams enc_params(Ctx& c, const std::string& n, const EncLayerW& w, cons
   q.pb_q1 = w.pb_q1; q.pb_qk2 = w.pb_qk2;
   q.film = c.film; q.film_bs = c.film_bs; q.film_tot = h->film_tot; q.f1 = w.f1; q.f2 = w.f2; q.f3 = w.f3;
   q.k1 = k1p; q.vt1 = vt1p; q.lpadT = h->lpadT; q.text = text;
-  q.x2 = BUF(c, n + ".x2"); q.qk2 = BUF(c, n + ".qk2"); q.vt2 = BUF(c, n + ".vt2"); q.lpadX = lpad;
-  q.out = BUF(c, n); q.pool = pool;
+  q.x2 = ELB(c, li, x2); q.qk2 = ELB(c, li, qk2); q.vt2 = ELB(c, li, vt2); q.lpadX = lpad;
+  q.out = ELB(c, li, out); q.pool = pool;
   return q;
 }
 
 // skip_a: this layer's enc_a half was already evaluated by the previous launch (EncChain); chain: what this layer's
 // enc_bc launch continues with (or null)
-void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
+void enc_layer(Ctx& c, int li, const EncLayerW& w, const void* x, int Lk, int lpad, const int64_t* text,
                void* pool, bool skip_a = false, const EncChain* chain = nullptr, int bm_min = 0) {
   dhw_handle* h = c.h;
   const int d = w.d;
-  const char* k1p = (const char*)BUF(c, n + (c.use_plane ? ".k1.T" : ".k1"));
-  const char* vt1p = (const char*)BUF(c, n + (c.use_plane ? ".vt1.T" : ".vt1"));
+  const char* k1p = (const char*)ELK(c, li, k1);
+  const char* vt1p = (const char*)ELK(c, li, vt1);
   if (c.use_plane) {
     k1p += (size_t)c.plane_step * c.B * c.Lt * d * h->es;
     vt1p += (size_t)c.plane_step * c.B * (v_rows(h, w) ? c.Lt : h->lpadT) * d * h->es;
   }
   if (h->fuse && enclayer_supported(h->prec, d, w.heads)) {
-    EncLayerParams q = enc_params(c, n, w, x, Lk, lpad, text, pool);
+    EncLayerParams q = enc_params(c, li, w, x, Lk, lpad, text, pool);
     q.bm_min = bm_min;
     const double rows = (double)c.B * Lk, dd = d;
     if (c.rec) {
@@ -931,10 +1002,10 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
       }
       Launch l(h, c.st, which == 0 ? "enc.fused_a" : (ch && ch->mode ? "enc.fused_bc+a" : "enc.fused_bc"), fl, by);
       hipError_t e = launch_enclayer(h->prec, q, which, c.st, ch);
-      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "enclayer %s/%d: %s", n.c_str(), which, hipGetErrorString(e));
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "enclayer %s/%d: %s", h->el_name[li].c_str(), which, hipGetErrorString(e));
     }
-    tap(c, n + ".x2", n + ".x2", Lk, d);
-    tap(c, n, n, Lk, d);
+    tap(c, tap_el(li, 1), ELB(c, li, x2), Lk, d);
+    tap(c, tap_el(li, 0), ELB(c, li, out), Lk, d);
     return;
   }
   if (c.rec) { c.rec_fail = true; return; }
@@ -944,107 +1015,107 @@ void enc_layer(Ctx& c, const std::string& n, const EncLayerW& w, const void* x, 
     p.bias0 = w.b_q1;
     p.posb = w.pb_q1;
     p.posb_cols = d;
-    p.out = BUF(c, n + ".q1");
+    p.out = ELB(c, li, q1);
     run_gemm(c, "enc.q_cross", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(c, n + ".q1"); a.ldq = d;
+    a.Q = ELB(c, li, q1); a.ldq = d;
     a.K = k1p; a.ldk = d; a.koff = 0;
     a.Vt = vt1p; a.lpad = h->lpadT;
     a.text = text; a.ldt = c.Lt;
-    a.out = BUF(c, n + ".a1"); a.ldo = d;
+    a.out = ELB(c, li, a1); a.ldo = d;
     a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = c.Lt;
     run_attn(c, "attn.cross", a);
   }
   {  // x2 = FiLM1(LN(dense(a1))) + x
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".a1"), w.w_d1, d, 1, 0};
+    p.seg[0] = GemmSeg{ELB(c, li, a1), w.w_d1, d, 1, 0};
     p.bias0 = w.b_d1;
     p.ln = 1;
     set_film(c, p, w.f1, 1);
     p.res2 = x;
-    p.out = BUF(c, n + ".x2");
+    p.out = ELB(c, li, x2);
     run_gemm(c, "enc.dense_cross", p);
   }
   {  // q2,k2 = W(x2 + PE), v2 = Wv x2
     GemmParams p = gp_base(c, Lk, 3 * d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".x2"), w.w_qkv2, d, 1, 0};
+    p.seg[0] = GemmSeg{ELB(c, li, x2), w.w_qkv2, d, 1, 0};
     p.bias0 = w.b_qkv2;
     p.posb = w.pb_qk2;
     p.posb_cols = 2 * d;
     p.n_store = 2 * d;
-    p.out = BUF(c, n + ".qk2");
-    p.vt = BUF(c, n + ".vt2");
+    p.out = ELB(c, li, qk2);
+    p.vt = ELB(c, li, vt2);
     p.vt_lpad = lpad;
     run_gemm(c, "enc.qkv_self", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(c, n + ".qk2"); a.ldq = 2 * d;
-    a.K = BUF(c, n + ".qk2"); a.ldk = 2 * d; a.koff = d;
-    a.Vt = BUF(c, n + ".vt2"); a.lpad = lpad;
+    a.Q = ELB(c, li, qk2); a.ldq = 2 * d;
+    a.K = ELB(c, li, qk2); a.ldk = 2 * d; a.koff = d;
+    a.Vt = ELB(c, li, vt2); a.lpad = lpad;
     a.text = nullptr;
-    a.out = BUF(c, n + ".a2"); a.ldo = d;
+    a.out = ELB(c, li, a2); a.ldo = d;
     a.B = c.B; a.H = w.heads; a.D = d / w.heads; a.Lq = Lk; a.Lk = Lk;
     run_attn(c, "attn.self", a);
   }
   {  // x3 = FiLM2(LN(x2 + dense(a2)))
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".a2"), w.w_d2, d, 1, 0};
+    p.seg[0] = GemmSeg{ELB(c, li, a2), w.w_d2, d, 1, 0};
     p.bias0 = w.b_d2;
-    p.res1 = BUF(c, n + ".x2");
+    p.res1 = ELB(c, li, x2);
     p.ln = 1;
     set_film(c, p, w.f2, 1);
-    p.out = BUF(c, n + ".x3");
+    p.out = ELB(c, li, x3);
     run_gemm(c, "enc.dense_self", p);
   }
   {  // f = SiLU(W1 SiLU(x3) + b1)
     GemmParams p = gp_base(c, Lk, 2 * d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".x3"), w.w_f1, d, 1, 1};
+    p.seg[0] = GemmSeg{ELB(c, li, x3), w.w_f1, d, 1, 1};
     p.bias0 = w.b_f1;
     p.silu_out = 1;
-    p.out = BUF(c, n + ".f");
+    p.out = ELB(c, li, f);
     run_gemm(c, "enc.ffn1", p);
   }
   {  // out = FiLM3(LN(W2 f + b2 + x3))
     GemmParams p = gp_base(c, Lk, d);
-    p.seg[0] = GemmSeg{BUF(c, n + ".f"), w.w_f2, 2 * d, 1, 0};
+    p.seg[0] = GemmSeg{ELB(c, li, f), w.w_f2, 2 * d, 1, 0};
     p.bias0 = w.b_f2;
-    p.res1 = BUF(c, n + ".x3");
+    p.res1 = ELB(c, li, x3);
     p.ln = 1;
     set_film(c, p, w.f3, 1);
-    p.out = BUF(c, n);
+    p.out = ELB(c, li, out);
     p.pool = pool;
     run_gemm(c, "enc.ffn2", p);
   }
-  tap(c, n + ".x2", n + ".x2", Lk, d);
-  tap(c, n + ".x3", n + ".x3", Lk, d);
-  tap(c, n, n, Lk, d);
+  tap(c, tap_el(li, 1), ELB(c, li, x2), Lk, d);
+  tap(c, tap_el(li, 2), ELB(c, li, x3), Lk, d);
+  tap(c, tap_el(li, 0), ELB(c, li, out), Lk, d);
 }
 
 // sigma-independent prefix of TextStyleEncoder (text_style.py:92-97 up to the LayerNorms; Dropout is identity in eval)
 void text_style_static(Ctx& c, const int64_t* text, const float* style) {
   dhw_handle* h = c.h;
   const int c2 = h->dims.c2, dt = 2 * c2;
-  RUN_SMALL(c, "cast.style", launch_cast(h->prec, style, (long)c.B * c.S5 * STYLE_CH, BUF(c, "sty_in"), c.st));
+  RUN_SMALL(c, "cast.style", launch_cast(h->prec, style, (long)c.B * c.S5 * STYLE_CH, WS(c, sty_in), c.st));
   {
     GemmParams p = gp_base(c, c.S5, 4 * c2);
-    p.seg[0] = GemmSeg{BUF(c, "sty_in"), h->w_sf1, STYLE_CH, 1, 1};
+    p.seg[0] = GemmSeg{WS(c, sty_in), h->w_sf1, STYLE_CH, 1, 1};
     p.bias0 = h->b_sf1;
     p.silu_out = 1;
-    p.out = BUF(c, "sty_h");
+    p.out = WS(c, sty_h);
     run_gemm(c, "style.ffn1", p);
   }
   {
     GemmParams p = gp_base(c, c.S5, dt);
-    p.seg[0] = GemmSeg{BUF(c, "sty_h"), h->w_sf3, 4 * c2, 1, 0};
+    p.seg[0] = GemmSeg{WS(c, sty_h), h->w_sf3, 4 * c2, 1, 0};
     p.bias0 = h->b_sf3;
     p.ln = 1;
-    p.out = BUF(c, "sty_n");
+    p.out = WS(c, sty_n);
     run_gemm(c, "style.ffn2_ln", p);
   }
-  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, true_width(h, dt), VOCAB, BUF(c, "t_n"), c.st));
+  RUN_SMALL(c, "embed_ln", launch_embed_ln(h->prec, text, c.B * c.Lt, h->emb, dt, true_width(h, dt), VOCAB, WS(c, t_n), c.st));
 }
 
 // sigma-dependent part of TextStyleEncoder (text_style.py:94-104) + the per-layer text projections
@@ -1053,18 +1124,17 @@ void text_style_dynamic(Ctx& c) {
   const int c2 = h->dims.c2, dt = 2 * c2;
   const float* g = c.film;
   const float* bt = c.film + h->film_tot;
-  const std::string& x = c.sfx;
   const int in_B = c.in_B ? c.in_B : c.B;
   if (h->fuse && h->fuse_text && textside_supported(h->prec, c.Lt, c.S5, dt)) {
     // one workgroup per (step, prompt) pair, every intermediate in LDS (textside.hip)
     TextStyleParams q{};
     q.n = c.B; q.in_B = in_B; q.Lt = c.Lt; q.S5 = c.S5;
-    q.sty_n = BUF(c, "sty_n"); q.t_n = BUF(c, "t_n");
+    q.sty_n = WS(c, sty_n); q.t_n = WS(c, t_n);
     q.film = c.film; q.film_bs = c.film_bs; q.film_div = c.film_div; q.film_tot = h->film_tot;
     q.f1 = h->f_ts1; q.f2 = h->f_ts2; q.f3 = h->f_ts3; q.f4 = h->f_ts4;
     q.w_q8 = h->w_q8; q.w_kv8 = h->w_kv8; q.w_d8 = h->w_d8; q.w_tf1 = h->w_tf1; q.w_tf3 = h->w_tf3;
     q.b_q8 = h->b_q8; q.b_kv8 = h->b_kv8; q.b_d8 = h->b_d8; q.b_tf1 = h->b_tf1; q.b_tf3 = h->b_tf3;
-    q.text_out = BUF(c, "text_out" + x);
+    q.text_out = TS(c, text_out);
     if (!c.err) {
       const double n = c.B, ddt = dt;
       Launch l(h, c.st, "ts.fused", n * (2.0 * c.S5 * ddt * 2 * ddt + 2.0 * c.Lt * ddt * ddt * 2 + 4.0 * c.Lt * c.S5 * ddt + 2.0 * c.Lt * ddt * 2 * ddt * 2),
@@ -1072,89 +1142,86 @@ void text_style_dynamic(Ctx& c) {
       hipError_t e = launch_text_style(h->prec, q, c.st);
       if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "text_style fused: %s", hipGetErrorString(e));
     }
-    if (x.empty()) tap(c, "text_style_model", "text_out", c.Lt, dt);
-    const char* nm[2] = {"enc3", "enc5"};
+    if (!c.planeT) tap(c, TAP_TS, TS(c, text_out), c.Lt, dt);
     for (size_t i = 0; i < h->el.size() && !c.err; ++i) {
-      const std::string ln = i < 2 ? nm[i] : "att_layers." + std::to_string(i - 2);
       const EncLayerW& w = h->el[i];
       TextLayerParams t{};
       t.n = c.B; t.Lt = c.Lt; t.d = w.d;
-      t.text_out = BUF(c, "text_out" + x);
+      t.text_out = TS(c, text_out);
       t.w_td = w.w_td; t.b_td = w.b_td;
       t.film = c.film; t.film_bs = c.film_bs; t.film_div = c.film_div; t.film_tot = h->film_tot; t.f0 = w.f0;
       t.w_kv = w.w_kv1; t.b_kv = w.b_kv1; t.pb_k1 = w.pb_k1;
-      t.k1 = BUF(c, ln + ".k1" + x); t.vt1 = BUF(c, ln + ".vt1" + x); t.lpadT = h->lpadT;
+      t.k1 = ELT(c, (int)i, k1); t.vt1 = ELT(c, (int)i, vt1); t.lpadT = h->lpadT;
+      if (c.err) break;
       t.pairs = h->text_pairs;
       const double n = c.B, dd = w.d;
       Launch l(h, c.st, "enc.text_fused", n * c.Lt * (2.0 * dt * dd + 4.0 * dd * dd), n * c.Lt * (dt + 2.0 * dd) * h->es + (dt * dd + 2.0 * dd * dd) * h->es);
       hipError_t e = launch_text_layer(h->prec, t, c.st);
-      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "text layer %s: %s", ln.c_str(), hipGetErrorString(e));
+      if (e != hipSuccess) c.err = fail(h, DHW_ERR_HIP, "text layer %s: %s", h->el_name[i].c_str(), hipGetErrorString(e));
     }
     return;
   }
-  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, BUF(c, "sty_n"), in_B, c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, c.film_div, BUF(c, "s1" + x), c.st));
-  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, BUF(c, "t_n"), in_B, c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, c.film_div, BUF(c, "t1" + x), c.st));
+  RUN_SMALL(c, "film.style", launch_film_apply(h->prec, WS(c, sty_n), in_B, c.B, c.S5, dt, g + h->f_ts1, bt + h->f_ts1, c.film_bs, c.film_div, TS(c, s1), c.st));
+  RUN_SMALL(c, "film.text", launch_film_apply(h->prec, WS(c, t_n), in_B, c.B, c.Lt, dt, g + h->f_ts2, bt + h->f_ts2, c.film_bs, c.film_div, TS(c, t1), c.st));
   {
     GemmParams p = gp_text(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "t1" + x), h->w_q8, dt, 1, 0};
+    p.seg[0] = GemmSeg{TS(c, t1), h->w_q8, dt, 1, 0};
     p.bias0 = h->b_q8;
-    p.out = BUF(c, "q8" + x);
+    p.out = TS(c, q8);
     run_gemm(c, "ts.q", p);
   }
   {
     GemmParams p = gp_base(c, c.S5, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(c, "s1" + x), h->w_kv8, dt, 1, 0};
+    p.seg[0] = GemmSeg{TS(c, s1), h->w_kv8, dt, 1, 0};
     p.bias0 = h->b_kv8;
     p.n_store = dt;
-    p.out = BUF(c, "k8" + x);
-    p.vt = BUF(c, "vt8" + x);
+    p.out = TS(c, k8);
+    p.vt = TS(c, vt8);
     p.vt_lpad = h->lpadS;
     run_gemm(c, "ts.kv", p);
   }
   {
     AttnParams a{};
-    a.Q = BUF(c, "q8" + x); a.ldq = dt;
-    a.K = BUF(c, "k8" + x); a.ldk = dt; a.koff = 0;
-    a.Vt = BUF(c, "vt8" + x); a.lpad = h->lpadS;
-    a.out = BUF(c, "a8" + x); a.ldo = dt;
+    a.Q = TS(c, q8); a.ldq = dt;
+    a.K = TS(c, k8); a.ldk = dt; a.koff = 0;
+    a.Vt = TS(c, vt8); a.lpad = h->lpadS;
+    a.out = TS(c, a8); a.ldo = dt;
     a.B = c.B; a.H = 8; a.D = dt / 8; a.Lq = c.Lt; a.Lk = c.S5;
     run_attn(c, "attn.text_style", a);
   }
   {
     GemmParams p = gp_text(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "a8" + x), h->w_d8, dt, 1, 0};
+    p.seg[0] = GemmSeg{TS(c, a8), h->w_d8, dt, 1, 0};
     p.bias0 = h->b_d8;
-    p.res1 = BUF(c, "t1" + x);
+    p.res1 = TS(c, t1);
     p.ln = 1;
     set_film(c, p, h->f_ts3, 1);
-    p.out = BUF(c, "t2" + x);
+    p.out = TS(c, t2);
     run_gemm(c, "ts.dense", p);
   }
   {
     GemmParams p = gp_text(c, c.Lt, 2 * dt);
-    p.seg[0] = GemmSeg{BUF(c, "t2" + x), h->w_tf1, dt, 1, 1};
+    p.seg[0] = GemmSeg{TS(c, t2), h->w_tf1, dt, 1, 1};
     p.bias0 = h->b_tf1;
     p.silu_out = 1;
-    p.out = BUF(c, "tf_h" + x);
+    p.out = TS(c, tf_h);
     run_gemm(c, "ts.ffn1", p);
   }
   {
     GemmParams p = gp_text(c, c.Lt, dt);
-    p.seg[0] = GemmSeg{BUF(c, "tf_h" + x), h->w_tf3, 2 * dt, 1, 0};
+    p.seg[0] = GemmSeg{TS(c, tf_h), h->w_tf3, 2 * dt, 1, 0};
     p.bias0 = h->b_tf3;
     p.ln = 1;
     set_film(c, p, h->f_ts4, 1);
-    p.out = BUF(c, "text_out" + x);
+    p.out = TS(c, text_out);
     run_gemm(c, "ts.ffn2", p);
   }
-  if (x.empty()) {
-    tap(c, "text_style_model.style", "s1", c.S5, dt);
-    tap(c, "text_style_model.t2", "t2", c.Lt, dt);
-    tap(c, "text_style_model", "text_out", c.Lt, dt);
+  if (!c.planeT) {
+    tap(c, TAP_TS_STYLE, TS(c, s1), c.S5, dt);
+    tap(c, TAP_TS_T2, TS(c, t2), c.Lt, dt);
+    tap(c, TAP_TS, TS(c, text_out), c.Lt, dt);
   }
-  const char* names[2] = {"enc3", "enc5"};
-  for (size_t i = 0; i < h->el.size(); ++i)
-    enc_layer_text(c, i < 2 ? names[i] : "att_layers." + std::to_string(i - 2), h->el[i]);
+  for (size_t i = 0; i < h->el.size(); ++i) enc_layer_text(c, (int)i, h->el[i]);
 }
 
 // the stroke path of DiffusionModel.forward (model.py:139-182); the heads are launched by the caller
@@ -1164,10 +1231,10 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   const int L = c.L, dt = 2 * d.c2;
   const bool fin = c.fuse_input && h->fuse;
   if (!fin) {
-    RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, BUF(c, "x0"), c.st));
-    tap(c, "input_dense", "x0", L, d.c1);
+    RUN_SMALL(c, "input_dense", launch_input_dense(h->prec, strokes, (long)c.B * L, h->in_w, h->in_b, d.c1, WS(c, x0), c.st));
+    tap(c, TAP_INPUT_DENSE, WS(c, x0), L, d.c1);
   }
-  conv_block(c, "enc1", h->enc1, BUF(c, "x0"), L, BUF(c, "enc1"), false, BUF(c, "enc1.pool"), fin ? strokes : nullptr);
+  conv_block(c, CB_ENC1, h->enc1, WS(c, x0), L, CBB(c, CB_ENC1, out), false, WS(c, enc1_pool), fin ? strokes : nullptr);
   // Everything between two self-attentions is row-local: enc2 / enc4 continue into the first half of enc3 / enc5,
   // enc5's second half into AvgPool + att_dense + the first attention layer's first half, and every attention layer's
   // second half into the next layer's first half.
@@ -1180,70 +1247,69 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   static const int conv_chain = getenv("DHW_CHAIN_CONV") ? atoi(getenv("DHW_CHAIN_CONV")) : 1;
   {
     EncChain ch{};
-    if (chain_ok && (conv_chain & 1)) { ch.mode = 1; ch.a = enc_params(c, "enc3", h->el[0], nullptr, L / 2, h->lpadX[0], text, nullptr); }
-    conv_block(c, "enc2", h->enc2, BUF(c, "enc1.pool"), L / 2, BUF(c, "enc2"), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a3);
+    if (chain_ok && (conv_chain & 1)) { ch.mode = 1; ch.a = enc_params(c, 0, h->el[0], nullptr, L / 2, h->lpadX[0], text, nullptr); }
+    conv_block(c, CB_ENC2, h->enc2, WS(c, enc1_pool), L / 2, CBB(c, CB_ENC2, out), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a3);
   }
-  enc_layer(c, "enc3", h->el[0], BUF(c, "enc2"), L / 2, h->lpadX[0], text, BUF(c, "enc3.pool"), a3);
+  enc_layer(c, 0, h->el[0], CBB(c, CB_ENC2, out), L / 2, h->lpadX[0], text, WS(c, enc3_pool), a3);
   {
     EncChain ch{};
-    if (chain_ok && (conv_chain & 2)) { ch.mode = 1; ch.a = enc_params(c, "enc5", h->el[1], nullptr, L / 4, h->lpadX[1], text, nullptr); }
-    conv_block(c, "enc4", h->enc4, BUF(c, "enc3.pool"), L / 4, BUF(c, "enc4"), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a5);
+    if (chain_ok && (conv_chain & 2)) { ch.mode = 1; ch.a = enc_params(c, 1, h->el[1], nullptr, L / 4, h->lpadX[1], text, nullptr); }
+    conv_block(c, CB_ENC4, h->enc4, WS(c, enc3_pool), L / 4, CBB(c, CB_ENC4, out), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a5);
   }
-  auto att_name = [](int i) { return "att_layers." + std::to_string(i); };
   EncChain ch5{};
   if (chain_ok && nl > 0 && enclayer_supported(h->prec, dt, h->el[2].heads) && enclayer_chain_supported(h->prec, d.c3, c.B, L / 4, 2, dt)) {
     ch5.mode = 2;
-    ch5.a = enc_params(c, att_name(0), h->el[2], nullptr, L / 8, h->lpadX[2], text, nullptr);
-    ch5.w_dense = h->w_attd; ch5.b_dense = h->b_attd; ch5.dense_out = BUF(c, "att_dense");
+    ch5.a = enc_params(c, 2, h->el[2], nullptr, L / 8, h->lpadX[2], text, nullptr);
+    ch5.w_dense = h->w_attd; ch5.b_dense = h->b_attd; ch5.dense_out = WS(c, att_dense);
   }
-  enc_layer(c, "enc5", h->el[1], BUF(c, "enc4"), L / 4, h->lpadX[1], text, BUF(c, "enc5.pool"), a5, ch5.mode ? &ch5 : nullptr,
+  enc_layer(c, 1, h->el[1], CBB(c, CB_ENC4, out), L / 4, h->lpadX[1], text, WS(c, enc5_pool), a5, ch5.mode ? &ch5 : nullptr,
             ch5.mode ? 32 : 0);
   if (!ch5.mode) {
     GemmParams p = gp_base(c, L / 8, dt);
-    p.seg[0] = GemmSeg{BUF(c, "enc5.pool"), h->w_attd, d.c3, 1, 0};
+    p.seg[0] = GemmSeg{WS(c, enc5_pool), h->w_attd, d.c3, 1, 0};
     p.bias0 = h->b_attd;
-    p.out = BUF(c, "att_dense");
+    p.out = WS(c, att_dense);
     run_gemm(c, "att_dense", p);
   }
-  tap(c, "att_dense", "att_dense", L / 8, dt);
-  const void* x = BUF(c, "att_dense");
+  tap(c, TAP_ATT_DENSE, WS(c, att_dense), L / 8, dt);
+  const void* x = WS(c, att_dense);
   bool a_done = ch5.mode != 0;   // this layer's first half was evaluated by the previous launch
   for (int i = 0; i < nl; ++i) {
-    const std::string n = att_name(i);
     EncChain chn{};
     if (chain_ok && i + 1 < nl && enclayer_chain_supported(h->prec, dt, c.B, L / 8, 1, dt)) {
       chn.mode = 1;
-      chn.a = enc_params(c, att_name(i + 1), h->el[3 + i], nullptr, L / 8, h->lpadX[2], text, nullptr);
+      chn.a = enc_params(c, 3 + i, h->el[3 + i], nullptr, L / 8, h->lpadX[2], text, nullptr);
     }
-    enc_layer(c, n, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr, a_done, chn.mode ? &chn : nullptr);
+    enc_layer(c, 2 + i, h->el[2 + i], x, L / 8, h->lpadX[2], text, nullptr, a_done, chn.mode ? &chn : nullptr);
     a_done = chn.mode != 0;
-    x = BUF(c, n);
+    x = ELB(c, 2 + i, out);
   }
-  struct UP { const char* name; const void* skip_in; void* w; float* b; int cin, cout, L; const void* low; const char* out; };
+  // decoder: x = Upsample(previous) + skip_conv(encoder output of the same resolution), then the ConvBlock (model.py:169-175)
+  struct UP { int tap; const void* skip_in; void* w; float* b; int cin, cout, L; const void* low; int cb; };
   const UP ups[3] = {
-      {"skip_conv3", BUF(c, "enc5"), h->w_sk3, h->b_sk3, d.c3, dt, L / 4, x, "xd3"},
-      {"skip_conv2", BUF(c, "enc3"), h->w_sk2, h->b_sk2, d.c2, d.c3, L / 2, BUF(c, "dec3"), "xd2"},
-      {"skip_conv1", BUF(c, "enc1"), h->w_sk1, h->b_sk1, d.c1, d.c2, L, BUF(c, "dec2"), "xd1"}};
+      {TAP_UP3, ELB(c, 1, out), h->w_sk3, h->b_sk3, d.c3, dt, L / 4, x, CB_DEC3},
+      {TAP_UP2, ELB(c, 0, out), h->w_sk2, h->b_sk2, d.c2, d.c3, L / 2, CBB(c, CB_DEC3, out), CB_DEC2},
+      {TAP_UP1, CBB(c, CB_ENC1, out), h->w_sk1, h->b_sk1, d.c1, d.c2, L, CBB(c, CB_DEC2, out), CB_DEC1}};
   const ConvBlockW* decs[3] = {&h->dec3, &h->dec2, &h->dec1};
-  const char* dn[3] = {"dec3", "dec2", "dec1"};
   const bool fup = h->fuse && h->fuse_up && h->prec == PREC_BF16;
   for (int i = 0; i < 3; ++i) {
     const UP& u = ups[i];
     if (fup) {   // the decoder block evaluates upsample(x) + skip_conv(h) while staging its input
       const UpIn in{u.skip_in, u.w, u.b, u.cin, u.low};
-      h->taps.erase(std::string(u.name) + "+up");
-      conv_block(c, dn[i], *decs[i], nullptr, u.L, BUF(c, dn[i]), i == 2, nullptr, nullptr, &in);
+      h->taps[u.tap].set = false;
+      conv_block(c, u.cb, *decs[i], nullptr, u.L, CBB(c, u.cb, out), i == 2, nullptr, nullptr, &in);
       continue;
     }
+    void* xd = need(c, c.ws->xd[i], "xd");
     GemmParams p = gp_base(c, u.L, u.cout);   // upsample(x) + skip_conv(h)  (model.py:169-175)
     p.seg[0] = GemmSeg{u.skip_in, u.w, u.cin, 3, 0};
     p.bias0 = u.b;
     p.res2 = u.low;
     p.res2_half = 1;
-    p.out = BUF(c, u.out);
+    p.out = xd;
     run_gemm(c, "skip_conv_up", p);
-    tap(c, std::string(u.name) + "+up", u.out, u.L, u.cout);
-    conv_block(c, dn[i], *decs[i], BUF(c, u.out), u.L, BUF(c, dn[i]), i == 2, nullptr);
+    tap(c, u.tap, xd, u.L, u.cout);
+    conv_block(c, u.cb, *decs[i], xd, u.L, CBB(c, u.cb, out), i == 2, nullptr);
   }
 }
 
@@ -1284,6 +1350,54 @@ void schedule_host(int T, std::vector<float>& beta, std::vector<float>& alpha) {
   }
 }
 
+
+
+void destroy_impl(dhw_handle* h);
+
+// Names are resolved HERE, once per handle: the EncoderLayers' module names and the table dhw_debug_read searches.
+void build_names(dhw_handle* h) {
+  const int nel = 2 + h->dims.num_layers;
+  h->el_name.clear();
+  h->el_name.push_back("enc3");
+  h->el_name.push_back("enc5");
+  for (int i = 0; i < h->dims.num_layers; ++i) h->el_name.push_back("att_layers." + std::to_string(i));
+  h->taps.assign(TAP_CONV0 + CB_N + 3 * nel, TapSlot{});
+  h->taps[TAP_SIGMA_FFN].name = "sigma_ffn";
+  h->taps[TAP_INPUT_DENSE].name = "input_dense";
+  h->taps[TAP_TS].name = "text_style_model";
+  h->taps[TAP_TS_STYLE].name = "text_style_model.style";
+  h->taps[TAP_TS_T2].name = "text_style_model.t2";
+  h->taps[TAP_ATT_DENSE].name = "att_dense";
+  h->taps[TAP_UP3].name = "skip_conv3+up";
+  h->taps[TAP_UP2].name = "skip_conv2+up";
+  h->taps[TAP_UP1].name = "skip_conv1+up";
+  for (int i = 0; i < CB_N; ++i) h->taps[tap_conv(i)].name = kConvName[i];
+  for (int li = 0; li < nel; ++li) {
+    h->taps[tap_el(li, 0)].name = h->el_name[li];
+    h->taps[tap_el(li, 1)].name = h->el_name[li] + ".x2";
+    h->taps[tap_el(li, 2)].name = h->el_name[li] + ".x3";
+  }
+}
+
+// Every per-call buffer of a freshly allocated workspace must exist (the all-steps plane comes later, ensure_plane): a buffer
+// the allocation code forgot is a dhw_create error, not something a launch discovers.
+int verify_workspace(dhw_handle* h, const Workspace& w) {
+  std::vector<std::pair<const char*, const void*>> all = {
+      {"sty_in", w.sty_in}, {"sty_h", w.sty_h}, {"sty_n", w.sty_n}, {"t_n", w.t_n}, {"s1", w.ts.s1}, {"k8", w.ts.k8}, {"vt8", w.ts.vt8},
+      {"t1", w.ts.t1}, {"q8", w.ts.q8}, {"a8", w.ts.a8}, {"t2", w.ts.t2}, {"tf_h", w.ts.tf_h}, {"text_out", w.ts.text_out}, {"x0", w.x0},
+      {"enc1.pool", w.enc1_pool}, {"enc3.pool", w.enc3_pool}, {"enc5.pool", w.enc5_pool}, {"att_dense", w.att_dense},
+      {"xd3", w.xd[0]}, {"xd2", w.xd[1]}, {"xd1", w.xd[2]}, {"x_t", w.d_xt}};
+  for (int i = 0; i < CB_N; ++i) { all.push_back({"convblock h1", w.cb[i].h1}); all.push_back({"convblock h2", w.cb[i].h2}); all.push_back({"convblock out", w.cb[i].out}); }
+  if ((int)w.el.size() != 2 + h->dims.num_layers) return fail(h, DHW_ERR_INTERNAL, "internal: workspace has %d EncoderLayers, the model %d", (int)w.el.size(), 2 + h->dims.num_layers);
+  for (const EncBufs& e : w.el)
+    for (auto kv : std::initializer_list<std::pair<const char*, const void*>>{{"tl", e.t.tl}, {"k1", e.t.k1}, {"vt1", e.t.vt1}, {"q1", e.q1}, {"a1", e.a1}, {"x2", e.x2},
+                                                                               {"qk2", e.qk2}, {"vt2", e.vt2}, {"a2", e.a2}, {"x3", e.x3}, {"f", e.f}, {"out", e.out}})
+      all.push_back(kv);
+  for (auto& kv : all)
+    if (!kv.second) return fail(h, DHW_ERR_INTERNAL, "internal: workspace buffer '%s' was not allocated", kv.first);
+  return 0;
+}
+
 }  // namespace
 
 // ================================================================= C-ABI
@@ -1294,85 +1408,106 @@ const char* dhw_version(void) { return "dhw-hip 0.1 (gfx950)"; }
 const char* dhw_last_error(dhw_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 int dhw_schedule(int T, float* beta_out, float* alpha_bar_out) {
-  if (T < 1 || !beta_out || !alpha_bar_out) return fail(nullptr, DHW_ERR_ARG, "dhw_schedule: bad args");
-  std::vector<float> b, a;
-  schedule_host(T, b, a);
-  std::memcpy(beta_out, b.data(), T * 4);
-  std::memcpy(alpha_bar_out, a.data(), T * 4);
-  return 0;
+  DHW_GUARD(nullptr, "dhw_schedule", int, {
+    if (T < 1 || !beta_out || !alpha_bar_out) return fail(nullptr, DHW_ERR_ARG, "dhw_schedule: bad args");
+    std::vector<float> b, a;
+    schedule_host(T, b, a);
+    std::memcpy(beta_out, b.data(), T * 4);
+    std::memcpy(alpha_bar_out, a.data(), T * 4);
+    return 0;
+  });
 }
 
 int dhw_create(dhw_handle** out, const dhw_dims* dims, int device) {
-  if (!out || !dims) return fail(nullptr, DHW_ERR_ARG, "dhw_create: null argument");
-  *out = nullptr;
-  const dhw_dims& d = *dims;
-  if (d.c1 != 128 || d.c3 != 256) return fail(nullptr, DHW_ERR_ARG, "c1 must be 128 and c3 256 (reference conditioning.py:9-10, model.py:103)");
-  if (d.c2 < 12 || d.c2 > 192 || d.c2 % 12)
-    return fail(nullptr, DHW_ERR_ARG, "c2 must be a multiple of 12 (model.py:88-106: 3 / 6 / 8 attention heads) and at most 192, the width the kernels are built for");
-  if (d.num_layers < 0 || d.num_layers > 16 || d.max_B < 1 || d.max_L < 8 || d.max_L % 8 || d.max_Lt < 1 || d.S < 1 || (d.S * 1280) % STYLE_CH)
-    return fail(nullptr, DHW_ERR_ARG, "dhw_create: bad dims");
-  if (d.precision != DHW_PREC_BF16 && d.precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "bad precision");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, DHW_ERR_HIP, "no HIP device available");
-  if (device < 0 || device >= ndev) return fail(nullptr, DHW_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
-  dhw_handle* h = new dhw_handle();
-  h->ldims = d;
-  h->dims = d;
-  h->dims.c2 = 192;
-  h->padded = d.c2 != 192;
-  h->device = device;
-  h->prec = d.precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
-  h->es = h->prec == PREC_F32 ? 4 : 2;
-  h->spec = build_spec(d.num_layers, d.c1, d.c2, d.c3);
-  h->pspec = build_spec(d.num_layers, d.c1, h->dims.c2, d.c3);
-  for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
-  h->host_w.resize(h->spec.size());
-  h->loaded.assign(h->spec.size(), 0);
-  build_film_layout(h);
-  if (hipSetDevice(device) != hipSuccess) { delete h; return fail(nullptr, DHW_ERR_HIP, "hipSetDevice failed"); }
-  {
-    const char* e = getenv("DHW_STREAMS");
-    if (e && atoi(e) >= 1) h->nstreams = std::min(atoi(e), MAX_STREAMS);
-    h->nstreams = std::max(1, std::min(h->nstreams, d.max_B));
-    h->nstreams_alloc = h->nstreams;
-  }
-  int rc = alloc_shared(h);
-  h->ws.resize(h->nstreams);
-  // ws[0] serves dhw_forward at the full batch; the others only ever see ceil(max_B / nstreams) prompts
-  for (int i = 0; !rc && i < h->nstreams; ++i)
-    rc = alloc_workspace(h, h->ws[i], i == 0 ? d.max_B : (d.max_B + h->nstreams - 1) / h->nstreams);
-  for (int i = 1; !rc && i < h->nstreams; ++i)
-    if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
-  if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
-  if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
-  if (const char* e = getenv("DHW_FUSE_TEXT")) h->fuse_text = atoi(e) != 0;
-  if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
-  if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
-  if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
-  if (const char* e = getenv("DHW_PERSIST")) h->persist = atoi(e) != 0;
-  if (const char* e = getenv("DHW_TEXT_PAIRS")) h->text_pairs = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
-  if (h->padded) h->fuse = false;   // (pad_weights: the fused block kernels have compile-time LayerNorm widths)
-  if (!rc && h->prec == PREC_BF16 && h->persist) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess || persist_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "persistent kernel setup failed: %s", hipGetErrorString(hipGetLastError()));
-    else {
-      h->persist_grid = prop.multiProcessorCount;
-      if (hipHostMalloc((void**)&h->h_step_err, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&h->d_step_err, h->h_step_err, 0) != hipSuccess)
-        rc = fail(h, DHW_ERR_HIP, "host-mapped error word: %s", hipGetErrorString(hipGetLastError()));
-      else *h->h_step_err = 0;
+  DHW_GUARD(nullptr, "dhw_create", int, {
+    if (!out || !dims) return fail(nullptr, DHW_ERR_ARG, "dhw_create: null argument");
+    *out = nullptr;
+    const dhw_dims& d = *dims;
+    if (d.c1 != 128 || d.c3 != 256) return fail(nullptr, DHW_ERR_ARG, "c1 must be 128 and c3 256 (reference conditioning.py:9-10, model.py:103)");
+    if (d.c2 < 12 || d.c2 > 192 || d.c2 % 12)
+      return fail(nullptr, DHW_ERR_ARG, "c2 must be a multiple of 12 (model.py:88-106: 3 / 6 / 8 attention heads) and at most 192, the width the kernels are built for");
+    if (d.num_layers < 0 || d.num_layers > 16 || d.max_B < 1 || d.max_L < 8 || d.max_L % 8 || d.max_Lt < 1 || d.S < 1 || (d.S * 1280) % STYLE_CH)
+      return fail(nullptr, DHW_ERR_ARG, "dhw_create: bad dims");
+    if (d.precision != DHW_PREC_BF16 && d.precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "bad precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, DHW_ERR_HIP, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, DHW_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    // (owned here until the handle is complete: an exception on the way — caught by the guard — must not leak it)
+    struct Hold {
+      dhw_handle* p;
+      ~Hold() { if (p) dhw_destroy(p); }
+    } hold{new dhw_handle()};
+    dhw_handle* h = hold.p;
+    h->ldims = d;
+    h->dims = d;
+    h->dims.c2 = 192;
+    h->padded = d.c2 != 192;
+    h->device = device;
+    h->prec = d.precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
+    h->es = h->prec == PREC_F32 ? 4 : 2;
+    h->spec = build_spec(d.num_layers, d.c1, d.c2, d.c3);
+    h->pspec = build_spec(d.num_layers, d.c1, h->dims.c2, d.c3);
+    for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
+    h->host_w.resize(h->spec.size());
+    h->loaded.assign(h->spec.size(), 0);
+    build_film_layout(h);
+    build_names(h);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DHW_ERR_HIP, "hipSetDevice failed");
+    {
+      const char* e = getenv("DHW_STREAMS");
+      if (e && atoi(e) >= 1) h->nstreams = std::min(atoi(e), MAX_STREAMS);
+      h->nstreams = std::max(1, std::min(h->nstreams, d.max_B));
+      h->nstreams_alloc = h->nstreams;
     }
-  }
-  if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
-  if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
-  if (!rc && textside_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
-  if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
-  if (rc) { g_err = h->err; dhw_destroy(h); return rc; }
-  *out = h;
-  return 0;
+    int rc = alloc_shared(h);
+    h->ws.resize(h->nstreams);
+    // ws[0] serves dhw_forward at the full batch; the others only ever see ceil(max_B / nstreams) prompts
+    for (int i = 0; !rc && i < h->nstreams; ++i)
+      if (!(rc = alloc_workspace(h, h->ws[i], i == 0 ? d.max_B : (d.max_B + h->nstreams - 1) / h->nstreams))) rc = verify_workspace(h, h->ws[i]);
+    for (int i = 1; !rc && i < h->nstreams; ++i)
+      if (hipStreamCreateWithFlags(&h->sub_streams[i], hipStreamNonBlocking) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "stream create failed");
+    if (const char* e = getenv("DHW_FUSE")) h->fuse = atoi(e) != 0;
+    if (const char* e = getenv("DHW_PLANE")) h->plane = atoi(e) != 0;
+    if (const char* e = getenv("DHW_FUSE_TEXT")) h->fuse_text = atoi(e) != 0;
+    if (const char* e = getenv("DHW_FUSE_HEADS")) h->fuse_heads = atoi(e) != 0;
+    if (const char* e = getenv("DHW_FUSE_UP")) h->fuse_up = atoi(e) != 0;
+    if (const char* e = getenv("DHW_CHAIN")) h->chain = atoi(e) != 0;
+    if (const char* e = getenv("DHW_PERSIST")) h->persist = atoi(e) != 0;
+    if (const char* e = getenv("DHW_TEXT_PAIRS")) h->text_pairs = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
+    if (h->padded) h->fuse = false;   // (pad_weights: the fused block kernels have compile-time LayerNorm widths)
+    if (!rc && h->prec == PREC_BF16 && h->persist) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) != hipSuccess || persist_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "persistent kernel setup failed: %s", hipGetErrorString(hipGetLastError()));
+      else {
+        h->persist_grid = prop.multiProcessorCount;
+        if (hipHostMalloc((void**)&h->h_step_err, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&h->d_step_err, h->h_step_err, 0) != hipSuccess)
+          rc = fail(h, DHW_ERR_HIP, "host-mapped error word: %s", hipGetErrorString(hipGetLastError()));
+        else *h->h_step_err = 0;
+      }
+    }
+    if (!rc && enclayer_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && convblock_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && textside_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && gemm_init() != hipSuccess) rc = fail(h, DHW_ERR_HIP, "kernel attribute setup failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc) { ErrBuf keep = h->err; g_err = keep; return rc; }   // (~Hold destroys the half-built handle; its message survives in the global slot)
+    hold.p = nullptr;
+    *out = h;
+    return 0;
+  });
 }
 
 void dhw_destroy(dhw_handle* h) {
   if (!h) return;
+  try {
+    destroy_impl(h);
+  } catch (...) {   // (nothing below is expected to throw; the ABI's promise holds regardless)
+  }
+}
+
+}  // extern "C"
+
+namespace {
+void destroy_impl(dhw_handle* h) {
   hipSetDevice(h->device);
   hipDeviceSynchronize();
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
@@ -1383,118 +1518,129 @@ void dhw_destroy(dhw_handle* h) {
   if (h->h_step_err) hipHostFree(h->h_step_err);
   delete h;
 }
+}  // namespace
+
+extern "C" {
 
 int dhw_num_keys(dhw_handle* h) { return h ? (int)h->spec.size() : DHW_ERR_ARG; }
 
 int dhw_key_info(dhw_handle* h, int i, const char** key, int64_t shape[3], int* ndim) {
-  if (!h || i < 0 || i >= (int)h->spec.size()) return fail(h, DHW_ERR_ARG, "dhw_key_info: index out of range");
-  const KeySpec& k = h->spec[i];
-  if (key) *key = k.key.c_str();
-  if (ndim) *ndim = (int)k.shape.size();
-  if (shape) for (size_t j = 0; j < 3; ++j) shape[j] = j < k.shape.size() ? k.shape[j] : 1;
-  return 0;
+  DHW_GUARD(h, "dhw_num_keys", int, {
+    if (!h || i < 0 || i >= (int)h->spec.size()) return fail(h, DHW_ERR_ARG, "dhw_key_info: index out of range");
+    const KeySpec& k = h->spec[i];
+    if (key) *key = k.key.c_str();
+    if (ndim) *ndim = (int)k.shape.size();
+    if (shape) for (size_t j = 0; j < 3; ++j) shape[j] = j < k.shape.size() ? k.shape[j] : 1;
+    return 0;
+  });
 }
 
 int dhw_load(dhw_handle* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
-  if (!h || !key || !host_ptr || !shape) return fail(h, DHW_ERR_ARG, "dhw_load: null argument");
-  auto it = h->key_index.find(key);
-  if (it == h->key_index.end()) return fail(h, DHW_ERR_KEY, "unexpected key in state_dict: %s", key);
-  const KeySpec& k = h->spec[it->second];
-  bool ok = ndim == (int)k.shape.size();
-  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == k.shape[i];
-  if (!ok) return fail(h, DHW_ERR_KEY, "size mismatch for %s", key);
-  size_t n = 1;
-  for (int64_t s : k.shape) n *= (size_t)s;
-  std::vector<float>& dst = h->host_w[it->second];
-  dst.resize(n);
-  switch (dtype) {
-    case DHW_F32: std::memcpy(dst.data(), host_ptr, n * 4); break;
-    case DHW_BF16: for (size_t i = 0; i < n; ++i) dst[i] = bf2f(((const uint16_t*)host_ptr)[i]); break;
-    case DHW_F16: for (size_t i = 0; i < n; ++i) dst[i] = h2f(((const uint16_t*)host_ptr)[i]); break;
-    case DHW_F64: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double*)host_ptr)[i]; break;
-    default: return fail(h, DHW_ERR_ARG, "dhw_load: unknown dtype %d", dtype);
-  }
-  h->loaded[it->second] = 1;
-  h->packed = false;
-  return 0;
+  DHW_GUARD(h, "dhw_load", int, {
+    if (!h || !key || !host_ptr || !shape) return fail(h, DHW_ERR_ARG, "dhw_load: null argument");
+    auto it = h->key_index.find(key);
+    if (it == h->key_index.end()) return fail(h, DHW_ERR_KEY, "unexpected key in state_dict: %s", key);
+    const KeySpec& k = h->spec[it->second];
+    bool ok = ndim == (int)k.shape.size();
+    for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == k.shape[i];
+    if (!ok) return fail(h, DHW_ERR_KEY, "size mismatch for %s", key);
+    size_t n = 1;
+    for (int64_t s : k.shape) n *= (size_t)s;
+    std::vector<float>& dst = h->host_w[it->second];
+    dst.resize(n);
+    switch (dtype) {
+      case DHW_F32: std::memcpy(dst.data(), host_ptr, n * 4); break;
+      case DHW_BF16: for (size_t i = 0; i < n; ++i) dst[i] = bf2f(((const uint16_t*)host_ptr)[i]); break;
+      case DHW_F16: for (size_t i = 0; i < n; ++i) dst[i] = h2f(((const uint16_t*)host_ptr)[i]); break;
+      case DHW_F64: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double*)host_ptr)[i]; break;
+      default: return fail(h, DHW_ERR_ARG, "dhw_load: unknown dtype %d", dtype);
+    }
+    h->loaded[it->second] = 1;
+    h->packed = false;
+    return 0;
+  });
 }
 
-int dhw_finalize(dhw_handle* h) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  if (h->packed) return 0;
-  for (size_t i = 0; i < h->spec.size(); ++i)
-    if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in state_dict: %s", h->spec[i].key.c_str());
-  HIPCK(h, hipSetDevice(h->device));
-  HIPCK(h, hipDeviceSynchronize());
-  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // device is idle here (synchronised above)
-  h->graphs.clear();
-  const dhw_dims& d = h->dims;
-  const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
-  int rc;
-  if (h->padded && (rc = pad_weights(h))) return rc;
-  // (re-packing leaks the previous packed copies until destroy; weights are loaded once in practice)
-  {  // FiLM: all gamma/beta projections concatenated -> [2*TOT, 32]
-    std::vector<float> w((size_t)2 * h->film_tot * SIG), b((size_t)2 * h->film_tot);
-    for (auto& kv : h->film_off) {
-      const auto& gw = W(h, kv.first + ".gamma_emb.weight");
-      const auto& gb = W(h, kv.first + ".gamma_emb.bias");
-      const auto& bw = W(h, kv.first + ".beta_emb.weight");
-      const auto& bb = W(h, kv.first + ".beta_emb.bias");
-      std::copy(gw.begin(), gw.end(), w.begin() + (size_t)kv.second * SIG);
-      std::copy(gb.begin(), gb.end(), b.begin() + kv.second);
-      std::copy(bw.begin(), bw.end(), w.begin() + (size_t)(h->film_tot + kv.second) * SIG);
-      std::copy(bb.begin(), bb.end(), b.begin() + h->film_tot + kv.second);
-    }
-    if ((rc = upload_f32(h, w, &h->d_film_w))) return rc;
-    if ((rc = upload_f32(h, b, &h->d_film_b))) return rc;
-  }
 #define UPF(dst, key) if ((rc = upload_f32(h, W(h, key), &h->dst))) return rc
-  UPF(sg_w1, "sigma_ffn.1.weight"); UPF(sg_b1, "sigma_ffn.1.bias"); UPF(sg_w2, "sigma_ffn.3.weight"); UPF(sg_b2, "sigma_ffn.3.bias");
-  UPF(in_w, "input_dense.weight"); UPF(in_b, "input_dense.bias");
-  UPF(out_w, "output_dense.weight"); UPF(out_b, "output_dense.bias");
-  UPF(pen_w, "pen_lifts_dense.0.weight"); UPF(pen_b, "pen_lifts_dense.0.bias");
-  UPF(emb, "text_style_model.emb.weight");
-  const std::string t = "text_style_model";
-  UPF(b_sf1, t + ".style_ffn.1.bias"); UPF(b_sf3, t + ".style_ffn.3.bias"); UPF(b_q8, t + ".mha.wq.bias");
-  UPF(b_d8, t + ".mha.dense.bias"); UPF(b_tf1, t + ".text_ffn.1.bias"); UPF(b_tf3, t + ".text_ffn.3.bias");
-  UPF(b_attd, "att_dense.bias"); UPF(b_sk1, "skip_conv1.bias"); UPF(b_sk2, "skip_conv2.bias"); UPF(b_sk3, "skip_conv3.bias");
-#undef UPF
-  if ((rc = upload_f32(h, vcat({&W(h, t + ".mha.wk.bias"), &W(h, t + ".mha.wv.bias")}), &h->b_kv8))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".style_ffn.1.weight"), 4 * c2, STYLE_CH, &h->w_sf1))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".style_ffn.3.weight"), dt, 4 * c2, &h->w_sf3))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".mha.wq.weight"), dt, dt, &h->w_q8))) return rc;
-  if ((rc = upload_packed(h, vcat({&W(h, t + ".mha.wk.weight"), &W(h, t + ".mha.wv.weight")}), 2 * dt, dt, &h->w_kv8))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".mha.dense.weight"), dt, dt, &h->w_d8))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".text_ffn.1.weight"), 2 * dt, dt, &h->w_tf1))) return rc;
-  if ((rc = upload_packed(h, W(h, t + ".text_ffn.3.weight"), dt, 2 * dt, &h->w_tf3))) return rc;
-  if ((rc = upload_packed(h, W(h, "att_dense.weight"), dt, 2 * c1, &h->w_attd))) return rc;
-  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv1.weight"), c2, c1), c2, 3 * c1, &h->w_sk1))) return rc;
-  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv2.weight"), c3, c2), c3, 3 * c2, &h->w_sk2))) return rc;
-  if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv3.weight"), dt, c3), dt, 3 * c3, &h->w_sk3))) return rc;
-  h->f_ts1 = h->film_off.at(t + ".affine1");
-  h->f_ts2 = h->film_off.at(t + ".affine2");
-  h->f_ts3 = h->film_off.at(t + ".affine3");
-  h->f_ts4 = h->film_off.at(t + ".affine4");
-  if ((rc = pack_convblock(h, "enc1", c1, c1, h->enc1))) return rc;
-  if ((rc = pack_convblock(h, "enc2", c1, c2, h->enc2))) return rc;
-  if ((rc = pack_convblock(h, "enc4", c2, c3, h->enc4))) return rc;
-  if ((rc = pack_convblock(h, "dec3", dt, c3, h->dec3))) return rc;
-  if ((rc = pack_convblock(h, "dec2", c3, c2, h->dec2))) return rc;
-  if ((rc = pack_convblock(h, "dec1", c2, c1, h->dec1))) return rc;
-  h->el.assign(2 + d.num_layers, EncLayerW{});
-  if ((rc = pack_enclayer(h, "enc3", c2, 3, 4.0f, d.max_L / 2, h->el[0]))) return rc;   // model.py:88
-  if ((rc = pack_enclayer(h, "enc5", c3, 4, 2.0f, d.max_L / 4, h->el[1]))) return rc;   // model.py:90
-  for (int i = 0; i < d.num_layers; ++i)
-    if ((rc = pack_enclayer(h, "att_layers." + std::to_string(i), dt, 6, 1.0f, d.max_L / 8, h->el[2 + i]))) return rc;   // model.py:104-109
-  HIPCK(h, hipDeviceSynchronize());
-  h->packed = true;
-  for (auto& kv : h->film_T) kv.second.ready = false;
-  return 0;
+int dhw_finalize(dhw_handle* h) {
+  DHW_GUARD(h, "dhw_finalize", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    if (h->packed) return 0;
+    for (size_t i = 0; i < h->spec.size(); ++i)
+      if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in state_dict: %s", h->spec[i].key.c_str());
+    HIPCK(h, hipSetDevice(h->device));
+    HIPCK(h, hipDeviceSynchronize());
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // device is idle here (synchronised above)
+    h->graphs.clear();
+    const dhw_dims& d = h->dims;
+    const int c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2;
+    int rc;
+    if (h->padded && (rc = pad_weights(h))) return rc;
+    // (re-packing leaks the previous packed copies until destroy; weights are loaded once in practice)
+    {  // FiLM: all gamma/beta projections concatenated -> [2*TOT, 32]
+      std::vector<float> w((size_t)2 * h->film_tot * SIG), b((size_t)2 * h->film_tot);
+      for (auto& kv : h->film_off) {
+        const auto& gw = W(h, kv.first + ".gamma_emb.weight");
+        const auto& gb = W(h, kv.first + ".gamma_emb.bias");
+        const auto& bw = W(h, kv.first + ".beta_emb.weight");
+        const auto& bb = W(h, kv.first + ".beta_emb.bias");
+        std::copy(gw.begin(), gw.end(), w.begin() + (size_t)kv.second * SIG);
+        std::copy(gb.begin(), gb.end(), b.begin() + kv.second);
+        std::copy(bw.begin(), bw.end(), w.begin() + (size_t)(h->film_tot + kv.second) * SIG);
+        std::copy(bb.begin(), bb.end(), b.begin() + h->film_tot + kv.second);
+      }
+      if ((rc = upload_f32(h, w, &h->d_film_w))) return rc;
+      if ((rc = upload_f32(h, b, &h->d_film_b))) return rc;
+    }
+    UPF(sg_w1, "sigma_ffn.1.weight"); UPF(sg_b1, "sigma_ffn.1.bias"); UPF(sg_w2, "sigma_ffn.3.weight"); UPF(sg_b2, "sigma_ffn.3.bias");
+    UPF(in_w, "input_dense.weight"); UPF(in_b, "input_dense.bias");
+    UPF(out_w, "output_dense.weight"); UPF(out_b, "output_dense.bias");
+    UPF(pen_w, "pen_lifts_dense.0.weight"); UPF(pen_b, "pen_lifts_dense.0.bias");
+    UPF(emb, "text_style_model.emb.weight");
+    const std::string t = "text_style_model";
+    UPF(b_sf1, t + ".style_ffn.1.bias"); UPF(b_sf3, t + ".style_ffn.3.bias"); UPF(b_q8, t + ".mha.wq.bias");
+    UPF(b_d8, t + ".mha.dense.bias"); UPF(b_tf1, t + ".text_ffn.1.bias"); UPF(b_tf3, t + ".text_ffn.3.bias");
+    UPF(b_attd, "att_dense.bias"); UPF(b_sk1, "skip_conv1.bias"); UPF(b_sk2, "skip_conv2.bias"); UPF(b_sk3, "skip_conv3.bias");
+    if ((rc = upload_f32(h, vcat({&W(h, t + ".mha.wk.bias"), &W(h, t + ".mha.wv.bias")}), &h->b_kv8))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".style_ffn.1.weight"), 4 * c2, STYLE_CH, &h->w_sf1))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".style_ffn.3.weight"), dt, 4 * c2, &h->w_sf3))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".mha.wq.weight"), dt, dt, &h->w_q8))) return rc;
+    if ((rc = upload_packed(h, vcat({&W(h, t + ".mha.wk.weight"), &W(h, t + ".mha.wv.weight")}), 2 * dt, dt, &h->w_kv8))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".mha.dense.weight"), dt, dt, &h->w_d8))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".text_ffn.1.weight"), 2 * dt, dt, &h->w_tf1))) return rc;
+    if ((rc = upload_packed(h, W(h, t + ".text_ffn.3.weight"), dt, 2 * dt, &h->w_tf3))) return rc;
+    if ((rc = upload_packed(h, W(h, "att_dense.weight"), dt, 2 * c1, &h->w_attd))) return rc;
+    if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv1.weight"), c2, c1), c2, 3 * c1, &h->w_sk1))) return rc;
+    if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv2.weight"), c3, c2), c3, 3 * c2, &h->w_sk2))) return rc;
+    if ((rc = upload_packed(h, conv_flat(W(h, "skip_conv3.weight"), dt, c3), dt, 3 * c3, &h->w_sk3))) return rc;
+    h->f_ts1 = film_offset(h, t + ".affine1");
+    h->f_ts2 = film_offset(h, t + ".affine2");
+    h->f_ts3 = film_offset(h, t + ".affine3");
+    h->f_ts4 = film_offset(h, t + ".affine4");
+    if ((rc = pack_convblock(h, "enc1", c1, c1, h->enc1))) return rc;
+    if ((rc = pack_convblock(h, "enc2", c1, c2, h->enc2))) return rc;
+    if ((rc = pack_convblock(h, "enc4", c2, c3, h->enc4))) return rc;
+    if ((rc = pack_convblock(h, "dec3", dt, c3, h->dec3))) return rc;
+    if ((rc = pack_convblock(h, "dec2", c3, c2, h->dec2))) return rc;
+    if ((rc = pack_convblock(h, "dec1", c2, c1, h->dec1))) return rc;
+    h->el.assign(2 + d.num_layers, EncLayerW{});
+    if ((rc = pack_enclayer(h, "enc3", c2, 3, 4.0f, d.max_L / 2, h->el[0]))) return rc;   // model.py:88
+    if ((rc = pack_enclayer(h, "enc5", c3, 4, 2.0f, d.max_L / 4, h->el[1]))) return rc;   // model.py:90
+    for (int i = 0; i < d.num_layers; ++i)
+      if ((rc = pack_enclayer(h, "att_layers." + std::to_string(i), dt, 6, 1.0f, d.max_L / 8, h->el[2 + i]))) return rc;   // model.py:104-109
+    HIPCK(h, hipDeviceSynchronize());
+    if (h->lookup_fail) return DHW_ERR_INTERNAL;   // (message set by W / film_offset)
+    h->packed = true;
+    for (auto& kv : h->film_T) kv.second.ready = false;
+    return 0;
+  });
 }
+
+#undef UPF
 
 static int launch_heads_for(Ctx& c, HeadsParams hp) {
   dhw_handle* h = c.h;
-  hp.x = (const float*)BUF(c, "dec1");
+  hp.x = (const float*)CBB(c, CB_DEC1, out);
   hp.rows = (long)c.B * c.L;
   hp.C = h->dims.c1;
   hp.w_out = h->out_w; hp.b_out = h->out_b; hp.w_pen = h->pen_w; hp.b_pen = h->pen_b;
@@ -1505,27 +1651,29 @@ static int launch_heads_for(Ctx& c, HeadsParams hp) {
 
 int dhw_forward(dhw_handle* h, const float* strokes, const int64_t* text, const float* sigma, const float* style,
                 int B, int L, int Lt, float* eps_out, float* pen_out, void* hip_stream) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  if (!strokes || !text || !sigma || !style || !eps_out || !pen_out) return fail(h, DHW_ERR_ARG, "dhw_forward: null pointer");
-  int rc = check_shapes(h, B, L, Lt);
-  if (rc) return rc;
-  if ((rc = dhw_finalize(h))) return rc;
-  HIPCK(h, hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)hip_stream;
-  Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
-  h->taps.clear();
-  RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(sigma, B, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32, st));
-  RUN_SMALL(c, "film_table", launch_film(h->d_sig32, B, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film, st));
-  h->taps["sigma_ffn"] = Tap{h->d_sig32, 1, SIG, true};
-  text_style_static(c, text, style);
-  text_style_dynamic(c);
-  stroke_path(c, strokes, text);
-  HeadsParams hp{};
-  hp.eps = eps_out;
-  hp.pen = pen_out;
-  launch_heads_for(c, hp);
-  h->last_B = B; h->last_L = L; h->last_Lt = Lt;
-  return c.err;
+  DHW_GUARD(h, "dhw_forward", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    if (!strokes || !text || !sigma || !style || !eps_out || !pen_out) return fail(h, DHW_ERR_ARG, "dhw_forward: null pointer");
+    int rc = check_shapes(h, B, L, Lt);
+    if (rc) return rc;
+    if ((rc = dhw_finalize(h))) return rc;
+    HIPCK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
+    taps_clear(h);
+    RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(sigma, B, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, h->d_sig32, st));
+    RUN_SMALL(c, "film_table", launch_film(h->d_sig32, B, h->d_film_w, h->d_film_b, 2 * h->film_tot, h->d_film, st));
+    tap(c, TAP_SIGMA_FFN, h->d_sig32, 1, SIG, true);
+    text_style_static(c, text, style);
+    text_style_dynamic(c);
+    stroke_path(c, strokes, text);
+    HeadsParams hp{};
+    hp.eps = eps_out;
+    hp.pen = pen_out;
+    launch_heads_for(c, hp);
+    h->last_B = B; h->last_L = L; h->last_Lt = Lt;
+    return c.err;
+  });
 }
 
 // sampler steps whose text side is precomputed together (bounds the plane's memory for long schedules)
@@ -1575,7 +1723,7 @@ static int sample_enqueue(dhw_handle* h, Workspace* w, int b0, int Bs, int B, co
       cp.film = h->d_film_T + (size_t)i * 2 * h->film_tot;   // step `step + k` uses schedule index i - k
       cp.film_bs = -2L * h->film_tot;
       cp.film_div = Bs;
-      cp.sfx = ".T";
+      cp.planeT = true;
       text_style_dynamic(cp);
       if (cp.err) return cp.err;
     }
@@ -1676,7 +1824,7 @@ static int sample_enqueue_all(dhw_handle* h, bool fork, int B, const int64_t* te
                               const std::vector<float>& beta, const std::vector<float>& alpha, const StepPlan* d_plans = nullptr) {
   const int ns = std::min(h->nstreams, B);
   const int per = (B + ns - 1) / ns;
-  h->taps.clear();
+  taps_clear(h);
   if (!fork || ns == 1) {
     for (int s = 0, b0 = 0; b0 < B; ++s, b0 += per) {
       int rc = sample_enqueue(h, &h->ws[s], b0, std::min(per, B - b0), B, text, style, L, Lt, T, mode, noise, out, st, beta, alpha, ns == 1 ? d_plans : nullptr);
@@ -1708,251 +1856,293 @@ static int sample_enqueue_all(dhw_handle* h, bool fork, int B, const int64_t* te
 
 int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, int L, int Lt, int T, int mode,
                const float* noise, uint64_t seed, int64_t first_sample, float* out, void* hip_stream) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  if (!text || !style || !out) return fail(h, DHW_ERR_ARG, "dhw_sample: null pointer");
-  if (T < 1 || (mode != 0 && mode != 1)) return fail(h, DHW_ERR_ARG, "dhw_sample: bad T/mode");
-  int rc = check_shapes(h, B, L, Lt);
-  if (rc) return rc;
-  if ((rc = dhw_finalize(h))) return rc;
-  HIPCK(h, hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)hip_stream;
-  if (h->h_step_err && *(volatile unsigned*)h->h_step_err) {
-    // a persistent step kernel gave up waiting (bounded spin, persist.h): its results were wrong; say so and fall back for good
-    const unsigned code = *(volatile unsigned*)h->h_step_err;
-    *(volatile unsigned*)h->h_step_err = 0;
-    h->persist = false;
-    hipDeviceSynchronize();
-    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
-    h->graphs.clear();
-    if (h->d_step_sync) hipMemset(h->d_step_sync, 0, h->step_sync_words * sizeof(unsigned));
-    return fail(h, DHW_ERR_HIP, "persistent step kernel timed out waiting for phase %u in an EARLIER call (its samples were invalid); "
-                "persistent launches are now disabled for this handle", code - 1);
-  }
-  dhw_handle::FilmT* ft = nullptr;
-  if ((rc = ensure_film_T(h, T, &ft))) return rc;
-  h->d_film_T = ft->d_film;
-  if (h->plane) {
-    const int ns = std::min(h->nstreams, B), per = (B + ns - 1) / ns;
-    for (int s = 0; s < ns; ++s)
-      if ((rc = ensure_plane(h, h->ws[s], plane_chunk(T), per))) return rc;
-  }
-  std::vector<float> beta, alpha;
-  schedule_host(T, beta, alpha);
-  if (!ft->ready) {
-    // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]; uploaded on the caller's
-    // stream from a buffer the handle owns, so it is ordered against everything else this call enqueues
-    ft->h_sigma.resize(T);
-    for (int i = 0; i < T; ++i) ft->h_sigma[i] = sqrtf(alpha[i]);   // inference.py:89
-    HIPCK(h, hipMemcpyAsync(ft->d_sigma, ft->h_sigma.data(), T * 4, hipMemcpyHostToDevice, st));
-    Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, ft->d_film, 0};
-    RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(ft->d_sigma, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, ft->d_sig32, st));
-    RUN_SMALL(c, "film_table", launch_film(ft->d_sig32, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, ft->d_film, st));
-    if (c.err) return c.err;
-    ft->ready = true;
-  }
-  {
-    hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, st);
-    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "set_seed: %s", hipGetErrorString(e));
-  }
-
-  // stage the caller's tensors into library-owned buffers (tiny D2D copies, outside the graph)
-  const size_t rows = (size_t)B * L;
-  HIPCK(h, hipMemcpyAsync(h->d_text_stage, text, (size_t)B * Lt * 8, hipMemcpyDeviceToDevice, st));
-  HIPCK(h, hipMemcpyAsync(h->d_style_stage, style, (size_t)B * h->dims.S * 1280 * 4, hipMemcpyDeviceToDevice, st));
-  const float* nz = nullptr;
-  if (noise) {
-    const size_t need = (size_t)(T + 1) * rows * 2;
-    if (need > h->noise_stage_cap) {
-      HIPCK(h, hipDeviceSynchronize());
-      for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // they captured the old staging pointer
+  DHW_GUARD(h, "dhw_sample", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    if (!text || !style || !out) return fail(h, DHW_ERR_ARG, "dhw_sample: null pointer");
+    if (T < 1 || (mode != 0 && mode != 1)) return fail(h, DHW_ERR_ARG, "dhw_sample: bad T/mode");
+    int rc = check_shapes(h, B, L, Lt);
+    if (rc) return rc;
+    if ((rc = dhw_finalize(h))) return rc;
+    HIPCK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (h->h_step_err && *(volatile unsigned*)h->h_step_err) {
+      // a persistent step kernel gave up waiting (bounded spin, persist.h): its results were wrong; say so and fall back for good
+      const unsigned code = *(volatile unsigned*)h->h_step_err;
+      *(volatile unsigned*)h->h_step_err = 0;
+      h->persist = false;
+      hipDeviceSynchronize();
+      for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
       h->graphs.clear();
-      h->plans.clear();   // (so did the step plans)
-      if ((rc = dev_alloc(h, (void**)&h->d_noise_stage, need * 4, false))) return rc;
-      h->noise_stage_cap = need;
+      if (h->d_step_sync) hipMemset(h->d_step_sync, 0, h->step_sync_words * sizeof(unsigned));
+      return fail(h, DHW_ERR_HIP, "persistent step kernel timed out waiting for phase %u in an EARLIER call (its samples were invalid); "
+                  "persistent launches are now disabled for this handle", code - 1);
     }
-    HIPCK(h, hipMemcpyAsync(h->d_noise_stage, noise, need * 4, hipMemcpyDeviceToDevice, st));
-    nz = h->d_noise_stage;
-  }
+    dhw_handle::FilmT* ft = nullptr;
+    if ((rc = ensure_film_T(h, T, &ft))) return rc;
+    h->d_film_T = ft->d_film;
+    if (h->plane) {
+      const int ns = std::min(h->nstreams, B), per = (B + ns - 1) / ns;
+      for (int s = 0; s < ns; ++s)
+        if ((rc = ensure_plane(h, h->ws[s], plane_chunk(T), per))) return rc;
+    }
+    std::vector<float> beta, alpha;
+    schedule_host(T, beta, alpha);
+    if (!ft->ready) {
+      // once per (weights, T): sigma_i = sqrt(abar_i) -> sigma MLP -> FiLM table [T, 2*TOT]; uploaded on the caller's
+      // stream from a buffer the handle owns, so it is ordered against everything else this call enqueues
+      ft->h_sigma.resize(T);
+      for (int i = 0; i < T; ++i) ft->h_sigma[i] = sqrtf(alpha[i]);   // inference.py:89
+      HIPCK(h, hipMemcpyAsync(ft->d_sigma, ft->h_sigma.data(), T * 4, hipMemcpyHostToDevice, st));
+      Ctx c{h, &h->ws[0], st, B, L, Lt, h->dims.S * 5, ft->d_film, 0};
+      RUN_SMALL(c, "sigma_ffn", launch_sigma_ffn(ft->d_sigma, T, h->sg_w1, h->sg_b1, h->sg_w2, h->sg_b2, ft->d_sig32, st));
+      RUN_SMALL(c, "film_table", launch_film(ft->d_sig32, T, h->d_film_w, h->d_film_b, 2 * h->film_tot, ft->d_film, st));
+      if (c.err) return c.err;
+      ft->ready = true;
+    }
+    {
+      hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, st);
+      if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "set_seed: %s", hipGetErrorString(e));
+    }
 
-  const bool graph = h->use_graph && !h->prof && !h->teach_every;
-  if (!graph) {
-    // eager launches: sub-batches still fork onto the side streams (concurrent kernels of different sub-batches);
-    // profiling keeps one stream so the per-launch events bracket one kernel each
-    rc = sample_enqueue_all(h, !h->prof, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
-  } else {
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain, (uint64_t)h->persist};
-    auto it = h->graphs.find(key);
-    if (it == h->graphs.end()) {
-      const StepPlan* d_plans = ensure_step_plans(h, key, B, L, Lt, T, mode, nz, beta, alpha);   // (before the capture: it uploads)
-      hipStream_t cs;
-      HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-      if (e != hipSuccess) { hipStreamDestroy(cs); return fail(h, DHW_ERR_HIP, "begin capture: %s", hipGetErrorString(e)); }
-      rc = sample_enqueue_all(h, true, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha, d_plans);
-      hipGraph_t g = nullptr;
-      e = hipStreamEndCapture(cs, &g);
-      if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
-      hipGraphExec_t ex = nullptr;
-      if (rc == 0) {
-        e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-        if (e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph instantiate failed: %s", hipGetErrorString(e));
+    // stage the caller's tensors into library-owned buffers (tiny D2D copies, outside the graph)
+    const size_t rows = (size_t)B * L;
+    HIPCK(h, hipMemcpyAsync(h->d_text_stage, text, (size_t)B * Lt * 8, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(h->d_style_stage, style, (size_t)B * h->dims.S * 1280 * 4, hipMemcpyDeviceToDevice, st));
+    const float* nz = nullptr;
+    if (noise) {
+      const size_t need = (size_t)(T + 1) * rows * 2;
+      if (need > h->noise_stage_cap) {
+        HIPCK(h, hipDeviceSynchronize());
+        for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);   // they captured the old staging pointer
+        h->graphs.clear();
+        h->plans.clear();   // (so did the step plans)
+        if ((rc = dev_alloc(h, (void**)&h->d_noise_stage, need * 4, false))) return rc;
+        h->noise_stage_cap = need;
       }
-      if (g) hipGraphDestroy(g);
-      hipStreamDestroy(cs);
-      if (rc) return rc;
-      it = h->graphs.emplace(key, ex).first;
+      HIPCK(h, hipMemcpyAsync(h->d_noise_stage, noise, need * 4, hipMemcpyDeviceToDevice, st));
+      nz = h->d_noise_stage;
     }
-    HIPCK(h, hipGraphLaunch(it->second, st));
-  }
-  if (rc == 0) HIPCK(h, hipMemcpyAsync(out, h->d_out_stage, rows * 3 * 4, hipMemcpyDeviceToDevice, st));
-  h->last_B = B; h->last_L = L; h->last_Lt = Lt;
-  return rc;
+
+    const bool graph = h->use_graph && !h->prof && !h->teach_every;
+    if (!graph) {
+      // eager launches: sub-batches still fork onto the side streams (concurrent kernels of different sub-batches);
+      // profiling keeps one stream so the per-launch events bracket one kernel each
+      rc = sample_enqueue_all(h, !h->prof, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, st, beta, alpha);
+    } else {
+      const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)Lt, (uint64_t)T, (uint64_t)mode, (uint64_t)(nz != nullptr), (uint64_t)h->nstreams, (uint64_t)h->plane, (uint64_t)h->fuse_heads, (uint64_t)h->fuse_up, (uint64_t)h->chain, (uint64_t)h->persist};
+      auto it = h->graphs.find(key);
+      if (it == h->graphs.end()) {
+        const StepPlan* d_plans = ensure_step_plans(h, key, B, L, Lt, T, mode, nz, beta, alpha);   // (before the capture: it uploads)
+        hipStream_t cs;
+        HIPCK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { hipStreamDestroy(cs); return fail(h, DHW_ERR_HIP, "begin capture: %s", hipGetErrorString(e)); }
+        rc = sample_enqueue_all(h, true, B, h->d_text_stage, h->d_style_stage, L, Lt, T, mode, nz, h->d_out_stage, cs, beta, alpha, d_plans);
+        hipGraph_t g = nullptr;
+        e = hipStreamEndCapture(cs, &g);
+        if (rc == 0 && e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t ex = nullptr;
+        if (rc == 0) {
+          e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+          if (e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "graph instantiate failed: %s", hipGetErrorString(e));
+        }
+        if (g) hipGraphDestroy(g);
+        hipStreamDestroy(cs);
+        if (rc) return rc;
+        it = h->graphs.emplace(key, ex).first;
+      }
+      HIPCK(h, hipGraphLaunch(it->second, st));
+    }
+    if (rc == 0) HIPCK(h, hipMemcpyAsync(out, h->d_out_stage, rows * 3 * 4, hipMemcpyDeviceToDevice, st));
+    h->last_B = B; h->last_L = L; h->last_Lt = Lt;
+    return rc;
+  });
 }
 
 int dhw_work(dhw_handle* h, int L, int Lt, double* flops_out, double* bytes_out) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  const dhw_dims& d = h->ldims;   // the model's own widths: zero padding (pad_weights) is not algorithmic work
-  const double c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2, S5 = d.S * 5;
-  auto cb = [](double L_, double ci, double co) { return 2 * L_ * (3 * ci * co + 1.5 * ci * co + 1.5 * co * co + co * co); };
-  auto el = [&](double Lk, double dm, double heads) {
-    double f = 2 * Lt * dt * dm + 2 * Lt * dm * dm * 2;            // text_dense, k1, v1
-    f += 2 * Lk * dm * dm * 2 + 2 * Lk * dm * dm * 4;              // q1, dense1, qkv2, dense2
-    f += 2 * Lk * dm * 2 * dm * 2;                                 // ffn
-    f += 4 * Lk * Lt * dm + 4 * Lk * Lk * dm;                      // SDPA cross + self
-    (void)heads;
-    return f;
-  };
-  double f = 0;
-  f += 2 * S5 * (STYLE_CH * 4 * c2 + 4 * c2 * dt) + 2 * Lt * dt * dt * 2 + 2 * S5 * dt * dt * 2 + 4 * Lt * S5 * dt + 2 * Lt * dt * 2 * dt * 2;
-  f += 2 * L * 2 * c1;
-  f += cb(L, c1, c1) + cb(L / 2, c1, c2) + cb(L / 4, c2, c3) + cb(L / 4, dt, c3) + cb(L / 2, c3, c2) + cb(L, c2, c1);
-  f += el(L / 2, c2, 3) + el(L / 4, c3, 4) + d.num_layers * el(L / 8, dt, 6);
-  f += 2 * (L / 8) * c3 * dt;
-  f += 2 * 3 * ((L / 4) * c3 * dt + (L / 2) * c2 * c3 + L * c1 * c2);
-  f += 2 * L * c1 * 3;
-  // block-boundary activation bytes: every top-level block reads its inputs and writes its outputs once
-  const double es = (double)h->es;
-  double by = 0;
-  by += L * 2 * 4 + L * 3 * 4;                                                  // strokes in, eps+pen out (fp32)
-  by += es * (L * c1 * 2 + (L / 2) * (c1 + c2) + (L / 4) * (c2 + c3) + (L / 4) * (dt + c3) + (L / 2) * (c3 + c2) + L * (c2 + c1));   // ConvBlocks
-  by += es * 2 * ((L / 2) * c2 + (L / 4) * c3 + d.num_layers * (L / 8) * dt);   // EncoderLayers
-  by += es * ((L / 8) * (c3 + dt));                                             // att_dense
-  by += es * ((L / 4) * (c3 + dt + dt) + (L / 2) * (c2 + c3 + c3) + L * (c1 + c2 + c2));   // skip convs + upsample add
-  by += es * (S5 * STYLE_CH + Lt * dt * (2 + 2 * (2 + d.num_layers)));          // text/style encoder + per-layer text reads
-  if (flops_out) *flops_out = f;
-  if (bytes_out) *bytes_out = by;
-  return 0;
+  DHW_GUARD(h, "dhw_work", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    const dhw_dims& d = h->ldims;   // the model's own widths: zero padding (pad_weights) is not algorithmic work
+    const double c1 = d.c1, c2 = d.c2, c3 = d.c3, dt = 2 * c2, S5 = d.S * 5;
+    auto cb = [](double L_, double ci, double co) { return 2 * L_ * (3 * ci * co + 1.5 * ci * co + 1.5 * co * co + co * co); };
+    auto el = [&](double Lk, double dm, double heads) {
+      double f = 2 * Lt * dt * dm + 2 * Lt * dm * dm * 2;            // text_dense, k1, v1
+      f += 2 * Lk * dm * dm * 2 + 2 * Lk * dm * dm * 4;              // q1, dense1, qkv2, dense2
+      f += 2 * Lk * dm * 2 * dm * 2;                                 // ffn
+      f += 4 * Lk * Lt * dm + 4 * Lk * Lk * dm;                      // SDPA cross + self
+      (void)heads;
+      return f;
+    };
+    double f = 0;
+    f += 2 * S5 * (STYLE_CH * 4 * c2 + 4 * c2 * dt) + 2 * Lt * dt * dt * 2 + 2 * S5 * dt * dt * 2 + 4 * Lt * S5 * dt + 2 * Lt * dt * 2 * dt * 2;
+    f += 2 * L * 2 * c1;
+    f += cb(L, c1, c1) + cb(L / 2, c1, c2) + cb(L / 4, c2, c3) + cb(L / 4, dt, c3) + cb(L / 2, c3, c2) + cb(L, c2, c1);
+    f += el(L / 2, c2, 3) + el(L / 4, c3, 4) + d.num_layers * el(L / 8, dt, 6);
+    f += 2 * (L / 8) * c3 * dt;
+    f += 2 * 3 * ((L / 4) * c3 * dt + (L / 2) * c2 * c3 + L * c1 * c2);
+    f += 2 * L * c1 * 3;
+    // block-boundary activation bytes: every top-level block reads its inputs and writes its outputs once
+    const double es = (double)h->es;
+    double by = 0;
+    by += L * 2 * 4 + L * 3 * 4;                                                  // strokes in, eps+pen out (fp32)
+    by += es * (L * c1 * 2 + (L / 2) * (c1 + c2) + (L / 4) * (c2 + c3) + (L / 4) * (dt + c3) + (L / 2) * (c3 + c2) + L * (c2 + c1));   // ConvBlocks
+    by += es * 2 * ((L / 2) * c2 + (L / 4) * c3 + d.num_layers * (L / 8) * dt);   // EncoderLayers
+    by += es * ((L / 8) * (c3 + dt));                                             // att_dense
+    by += es * ((L / 4) * (c3 + dt + dt) + (L / 2) * (c2 + c3 + c3) + L * (c1 + c2 + c2));   // skip convs + upsample add
+    by += es * (S5 * STYLE_CH + Lt * dt * (2 + 2 * (2 + d.num_layers)));          // text/style encoder + per-layer text reads
+    if (flops_out) *flops_out = f;
+    if (bytes_out) *bytes_out = by;
+    return 0;
+  });
 }
 
 // ---------------------------------------------------------------- debug / measurement hooks
 int64_t dhw_debug_read(dhw_handle* h, const char* name, float* host_dst, int64_t max_floats, int64_t shape_out[3]) {
-  if (!h || !name || !host_dst) return fail(h, DHW_ERR_ARG, "dhw_debug_read: null argument");
-  auto it = h->taps.find(name);
-  if (it == h->taps.end()) return fail(h, DHW_ERR_ARG, "no activation named %s", name);
-  const Tap& t = it->second;
-  const int64_t n = (int64_t)h->last_B * t.rows * t.cols;
-  if (n > max_floats) return fail(h, DHW_ERR_ARG, "buffer too small for %s", name);
-  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(h, DHW_ERR_HIP, "sync failed: %s", hipGetErrorString(hipGetLastError()));
-  if (shape_out) { shape_out[0] = h->last_B; shape_out[1] = t.rows; shape_out[2] = t.cols; }
-  if (t.f32 || h->prec == PREC_F32) {
-    if (hipMemcpy(host_dst, t.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
-  } else {
-    std::vector<uint16_t> tmp(n);
-    if (hipMemcpy(tmp.data(), t.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
-    for (int64_t i = 0; i < n; ++i) host_dst[i] = bf2f(tmp[i]);
-  }
-  return n;
+  DHW_GUARD(h, "dhw_debug_read", int64_t, {
+    if (!h || !name || !host_dst) return fail(h, DHW_ERR_ARG, "dhw_debug_read: null argument");
+    const Tap* tp = nullptr;
+    for (const TapSlot& sl : h->taps)
+      if (sl.set && sl.name == name) tp = &sl.t;
+    if (!tp) return fail(h, DHW_ERR_ARG, "no activation named %s", name);
+    const Tap& t = *tp;
+    const int64_t n = (int64_t)h->last_B * t.rows * t.cols;
+    if (n > max_floats) return fail(h, DHW_ERR_ARG, "buffer too small for %s", name);
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(h, DHW_ERR_HIP, "sync failed: %s", hipGetErrorString(hipGetLastError()));
+    if (shape_out) { shape_out[0] = h->last_B; shape_out[1] = t.rows; shape_out[2] = t.cols; }
+    if (t.f32 || h->prec == PREC_F32) {
+      if (hipMemcpy(host_dst, t.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+    } else {
+      std::vector<uint16_t> tmp(n);
+      if (hipMemcpy(tmp.data(), t.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+      for (int64_t i = 0; i < n; ++i) host_dst[i] = bf2f(tmp[i]);
+    }
+    return n;
+  });
 }
 
 int dhw_debug_xcd_swizzle(int block_id, int nwg) { return xcd_swizzle(block_id, nwg); }
 
+// Tests of the no-throw barrier itself (needs no device, handle may be null): raise a C++ exception INSIDE the guarded body of an
+// entry point, exactly where a std::map::at / vector::resize / new of the host code would.  Must come back as DHW_ERR_INTERNAL.
+int dhw_debug_raise(dhw_handle* h, int kind) {
+  DHW_GUARD(h, "dhw_debug_raise", int, {
+    if (kind == DHW_RAISE_OUT_OF_RANGE) {
+      std::map<std::string, int> m;
+      return m.at("a buffer that was never allocated");
+    }
+    if (kind == DHW_RAISE_BAD_ALLOC) throw std::bad_alloc();
+    if (kind == DHW_RAISE_UNKNOWN) throw 42;
+    return fail(h, DHW_ERR_ARG, "dhw_debug_raise: kind %d", kind);
+  });
+}
+
 int dhw_debug_randn(dhw_handle* h, uint64_t seed, int64_t first_sample, int B, int L, int iter, float* host_dst) {
-  if (!h || !host_dst || B < 1 || L < 1 || iter < -1 || (long)B * L > (long)h->dims.max_B * h->dims.max_L)
-    return fail(h, DHW_ERR_ARG, "dhw_debug_randn: bad argument");
-  HIPCK(h, hipSetDevice(h->device));
-  HIPCK(h, hipDeviceSynchronize());
-  const long rows = (long)B * L;
-  hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, nullptr);
-  if (e == hipSuccess) e = launch_randn_init(h->ws[0].d_xt, rows, L, h->d_seed, 0, nullptr, iter);
-  if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "randn: %s", hipGetErrorString(e));
-  HIPCK(h, hipMemcpy(host_dst, h->ws[0].d_xt, rows * 2 * 4, hipMemcpyDeviceToHost));
-  return 0;
+  DHW_GUARD(h, "dhw_debug_xcd_swizzle", int, {
+    if (!h || !host_dst || B < 1 || L < 1 || iter < -1 || (long)B * L > (long)h->dims.max_B * h->dims.max_L)
+      return fail(h, DHW_ERR_ARG, "dhw_debug_randn: bad argument");
+    HIPCK(h, hipSetDevice(h->device));
+    HIPCK(h, hipDeviceSynchronize());
+    const long rows = (long)B * L;
+    hipError_t e = launch_set_seed(h->d_seed, seed, first_sample, nullptr);
+    if (e == hipSuccess) e = launch_randn_init(h->ws[0].d_xt, rows, L, h->d_seed, 0, nullptr, iter);
+    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "randn: %s", hipGetErrorString(e));
+    HIPCK(h, hipMemcpy(host_dst, h->ws[0].d_xt, rows * 2 * 4, hipMemcpyDeviceToHost));
+    return 0;
+  });
 }
 
 int dhw_profile_enable(dhw_handle* h, int on) {
-  if (!h) return DHW_ERR_ARG;
-  h->prof = on != 0;
-  return 0;
+  DHW_GUARD(h, "dhw_profile_enable", int, {
+    if (!h) return DHW_ERR_ARG;
+    h->prof = on != 0;
+    return 0;
+  });
 }
 int dhw_profile_reset(dhw_handle* h) {
-  if (!h) return DHW_ERR_ARG;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
-  for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-  h->prof_recs.clear();
-  h->prof_agg.clear();
-  return 0;
+  DHW_GUARD(h, "dhw_profile_reset", int, {
+    if (!h) return DHW_ERR_ARG;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto& r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    h->prof_recs.clear();
+    h->prof_agg.clear();
+    return 0;
+  });
 }
 int dhw_profile_count(dhw_handle* h) {
-  if (!h) return DHW_ERR_ARG;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
-  h->prof_agg.assign(h->prof_labels.size(), ProfAgg{});
-  for (size_t i = 0; i < h->prof_labels.size(); ++i) h->prof_agg[i].label = h->prof_labels[i];
-  for (auto& r : h->prof_recs) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-    ProfAgg& a = h->prof_agg[r.label];
-    a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.n += 1;
-  }
-  return (int)h->prof_agg.size();
+  DHW_GUARD(h, "dhw_profile_count", int, {
+    if (!h) return DHW_ERR_ARG;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    h->prof_agg.assign(h->prof_labels.size(), ProfAgg{});
+    for (size_t i = 0; i < h->prof_labels.size(); ++i) h->prof_agg[i].label = h->prof_labels[i];
+    for (auto& r : h->prof_recs) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+      ProfAgg& a = h->prof_agg[r.label];
+      a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.n += 1;
+    }
+    return (int)h->prof_agg.size();
+  });
 }
 int dhw_profile_get(dhw_handle* h, int i, const char** label, double* total_ms, int64_t* launches, double* flops_sum,
                     double* bytes_sum) {
-  if (!h || i < 0 || i >= (int)h->prof_agg.size()) return DHW_ERR_ARG;
-  const ProfAgg& a = h->prof_agg[i];
-  if (label) *label = a.label.c_str();
-  if (total_ms) *total_ms = a.ms;
-  if (launches) *launches = a.n;
-  if (flops_sum) *flops_sum = a.flops;
-  if (bytes_sum) *bytes_sum = a.bytes;
-  return 0;
+  DHW_GUARD(h, "dhw_profile_get", int, {
+    if (!h || i < 0 || i >= (int)h->prof_agg.size()) return DHW_ERR_ARG;
+    const ProfAgg& a = h->prof_agg[i];
+    if (label) *label = a.label.c_str();
+    if (total_ms) *total_ms = a.ms;
+    if (launches) *launches = a.n;
+    if (flops_sum) *flops_sum = a.flops;
+    if (bytes_sum) *bytes_sum = a.bytes;
+    return 0;
+  });
 }
 int dhw_set_streams(dhw_handle* h, int n) {
-  if (!h || n < 1) return DHW_ERR_ARG;
-  h->nstreams = std::min(n, h->nstreams_alloc);
-  return h->nstreams;
+  DHW_GUARD(h, "dhw_set_streams", int, {
+    if (!h || n < 1) return DHW_ERR_ARG;
+    h->nstreams = std::min(n, h->nstreams_alloc);
+    return h->nstreams;
+  });
 }
 // shapes of dhw_sample that run as one persistent launch per denoiser call (persist.h): cached plans that are in use
 int dhw_debug_persist_plans(dhw_handle* h) {
-  if (!h) return DHW_ERR_ARG;
-  int n = 0;
-  for (auto& kv : h->plans) n += kv.second.ok ? 1 : 0;
-  return n;
+  DHW_GUARD(h, "dhw_debug_persist_plans", int, {
+    if (!h) return DHW_ERR_ARG;
+    int n = 0;
+    for (auto& kv : h->plans) n += kv.second.ok ? 1 : 0;
+    return n;
+  });
 }
 // diagnostics: the stamps of the last persistent step (see persist.hip, PTRACE) -> host_dst[workgroups * STEP_MAX_PHASES * 4]; returns
 // the number of workgroups (0 = no trace buffer: DHW_PERSIST_TRACE was not set when the plans were built)
 int dhw_debug_persist_trace(dhw_handle* h, unsigned long long* host_dst, int64_t max_words) {
-  if (!h || !host_dst) return DHW_ERR_ARG;
-  if (!h->d_step_trace) return 0;
-  const int64_t n = (int64_t)h->persist_grid * STEP_MAX_PHASES * 4;
-  if (max_words < n) return DHW_ERR_ARG;
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_dst, h->d_step_trace, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return DHW_ERR_HIP;
-  return h->persist_grid;
+  DHW_GUARD(h, "dhw_debug_persist_trace", int, {
+    if (!h || !host_dst) return DHW_ERR_ARG;
+    if (!h->d_step_trace) return 0;
+    const int64_t n = (int64_t)h->persist_grid * STEP_MAX_PHASES * 4;
+    if (max_words < n) return DHW_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_dst, h->d_step_trace, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return DHW_ERR_HIP;
+    return h->persist_grid;
+  });
 }
 int dhw_set_graph(dhw_handle* h, int on) {
-  if (!h) return DHW_ERR_ARG;
-  h->use_graph = on != 0;
-  return 0;
+  DHW_GUARD(h, "dhw_set_graph", int, {
+    if (!h) return DHW_ERR_ARG;
+    h->use_graph = on != 0;
+    return 0;
+  });
 }
 
 int dhw_debug_set_teacher(dhw_handle* h, const float* reset_dev, float* capture_dev, int every) {
-  if (!h) return DHW_ERR_ARG;
-  if (every < 0 || (every > 0 && (!reset_dev || !capture_dev))) return fail(h, DHW_ERR_ARG, "dhw_debug_set_teacher: bad arguments");
-  h->teach_every = every;
-  h->teach_reset = every ? reset_dev : nullptr;
-  h->teach_capture = every ? capture_dev : nullptr;
-  return 0;
+  DHW_GUARD(h, "dhw_debug_set_teacher", int, {
+    if (!h) return DHW_ERR_ARG;
+    if (every < 0 || (every > 0 && (!reset_dev || !capture_dev))) return fail(h, DHW_ERR_ARG, "dhw_debug_set_teacher: bad arguments");
+    h->teach_every = every;
+    h->teach_reset = every ? reset_dev : nullptr;
+    h->teach_capture = every ? capture_dev : nullptr;
+    return 0;
+  });
 }
 
 }  // extern "C"

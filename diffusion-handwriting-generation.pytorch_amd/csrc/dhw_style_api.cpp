@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/dhw_style.h"
+#include "abi_guard.h"
 #include "dhw_kernels.h"
 
 namespace {
@@ -80,13 +81,14 @@ float bf2f(uint16_t h) {
   return f;
 }
 
-std::string g_err;
+ErrBuf g_err;
 
 }  // namespace
 
 struct dhw_style {
   int device = 0, prec = PREC_BF16, es = 2;
-  std::string err;
+  ErrBuf err;
+  bool lookup_fail = false;   // the packing code asked for a key build_keys does not declare
   std::vector<SKey> spec;
   std::map<std::string, int> key_index;
   std::vector<std::vector<float>> host_w;
@@ -113,15 +115,16 @@ struct dhw_style {
 
 namespace {
 
-int fail(dhw_style* h, int code, const char* fmt, ...) {
-  char tmp[512];
+int fail(dhw_style* h, int code, const char* fmt, ...) noexcept {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  (h ? h->err : g_err).vsetf(fmt, ap);
   va_end(ap);
-  (h ? h->err : g_err) = tmp;
   return code;
 }
+// the body of every extern "C" entry point runs inside this: no exception leaves the library (abi_guard.h)
+#define STYLE_GUARD(h, fn, R, ...) \
+  return abi_guard<R>(fn, [&](const char* f_, const char* w_) { return fail((h), DHW_ERR_INTERNAL, "%s: internal error: %s", f_, w_); }, [&]() -> R __VA_ARGS__)
 
 #define SHIP(h, call)                                                                                        \
   do {                                                                                                       \
@@ -162,7 +165,17 @@ int upload_packed(dhw_style* h, const std::vector<float>& wf, int N, int K, void
   return 0;
 }
 
-const std::vector<float>& W(dhw_style* h, const std::string& k) { return h->host_w[h->key_index.at(k)]; }
+// (finalize-time only; a miss is a programming error: recorded, finalize returns DHW_ERR_INTERNAL, nothing throws)
+const std::vector<float>& W(dhw_style* h, const std::string& k) {
+  static const std::vector<float> none(4096, 0.f);   // (long enough for every per-channel read of the packing loops)
+  auto it = h->key_index.find(k);
+  if (it == h->key_index.end()) {
+    if (!h->lookup_fail) fail(h, DHW_ERR_INTERNAL, "internal: the packing code asked for an unknown weight '%s'", k.c_str());
+    h->lookup_fail = true;
+    return none;
+  }
+  return h->host_w[it->second];
+}
 
 // eval-mode BatchNorm2d as a per-channel affine: y = x * scale + shift
 void bn_affine(dhw_style* h, const std::string& n, int c, std::vector<float>& scale, std::vector<float>& shift) {
@@ -246,170 +259,189 @@ extern "C" {
 const char* dhw_style_last_error(dhw_style* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 int dhw_style_create(dhw_style** out, int precision, int device) {
-  if (!out) return fail(nullptr, DHW_ERR_ARG, "dhw_style_create: null out");
-  *out = nullptr;
-  if (precision != DHW_PREC_BF16 && precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "dhw_style_create: bad precision %d", precision);
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= device || device < 0)
-    return fail(nullptr, DHW_ERR_HIP, "no HIP device %d (the StyleExtractor has no CPU path)", device);
-  dhw_style* h = new dhw_style;
-  h->device = device;
-  h->prec = precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
-  h->es = h->prec == PREC_F32 ? 4 : 2;
-  h->spec = build_keys();
-  for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
-  h->host_w.resize(h->spec.size());
-  h->loaded.assign(h->spec.size(), 0);
-  if (hipSetDevice(device) != hipSuccess || gemm_init() != hipSuccess) {
-    delete h;
-    return fail(nullptr, DHW_ERR_HIP, "device setup failed: %s", hipGetErrorString(hipGetLastError()));
-  }
-  *out = h;
-  return 0;
+  STYLE_GUARD(nullptr, "dhw_style_create", int, {
+    if (!out) return fail(nullptr, DHW_ERR_ARG, "dhw_style_create: null out");
+    *out = nullptr;
+    if (precision != DHW_PREC_BF16 && precision != DHW_PREC_F32) return fail(nullptr, DHW_ERR_ARG, "dhw_style_create: bad precision %d", precision);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device || device < 0)
+      return fail(nullptr, DHW_ERR_HIP, "no HIP device %d (the StyleExtractor has no CPU path)", device);
+    struct Hold {
+      dhw_style* p;
+      ~Hold() { delete p; }
+    } hold{new dhw_style};
+    dhw_style* h = hold.p;
+    h->device = device;
+    h->prec = precision == DHW_PREC_F32 ? PREC_F32 : PREC_BF16;
+    h->es = h->prec == PREC_F32 ? 4 : 2;
+    h->spec = build_keys();
+    for (size_t i = 0; i < h->spec.size(); ++i) h->key_index[h->spec[i].key] = (int)i;
+    h->host_w.resize(h->spec.size());
+    h->loaded.assign(h->spec.size(), 0);
+    if (hipSetDevice(device) != hipSuccess || gemm_init() != hipSuccess)
+      return fail(nullptr, DHW_ERR_HIP, "device setup failed: %s", hipGetErrorString(hipGetLastError()));
+    hold.p = nullptr;
+    *out = h;
+    return 0;
+  });
 }
 
 void dhw_style_destroy(dhw_style* h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
-  for (void* p : h->allocs) hipFree(p);
-  delete h;
+  try {
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    delete h;
+  } catch (...) {
+  }
 }
 
 int dhw_style_num_keys(dhw_style* h) { return h ? (int)h->spec.size() : DHW_ERR_ARG; }
 
 int dhw_style_key_info(dhw_style* h, int i, const char** key, int64_t shape[4], int* ndim) {
-  if (!h || i < 0 || i >= (int)h->spec.size()) return DHW_ERR_ARG;
-  if (key) *key = h->spec[i].key.c_str();
-  if (ndim) *ndim = (int)h->spec[i].shape.size();
-  if (shape)
-    for (size_t k = 0; k < h->spec[i].shape.size(); ++k) shape[k] = h->spec[i].shape[k];
-  return 0;
+  STYLE_GUARD(h, "dhw_style_key_info", int, {
+    if (!h || i < 0 || i >= (int)h->spec.size()) return DHW_ERR_ARG;
+    if (key) *key = h->spec[i].key.c_str();
+    if (ndim) *ndim = (int)h->spec[i].shape.size();
+    if (shape)
+      for (size_t k = 0; k < h->spec[i].shape.size(); ++k) shape[k] = h->spec[i].shape[k];
+    return 0;
+  });
 }
 
 int dhw_style_load(dhw_style* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
-  if (!h || !key || !host_ptr || (!shape && ndim > 0)) return fail(h, DHW_ERR_ARG, "dhw_style_load: null argument");
-  const std::string k = key;
-  // the parts of torchvision's MobileNetV2 state_dict the feature extractor does not use
-  if (k.rfind("classifier.", 0) == 0 || (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0)) return 0;
-  auto it = h->key_index.find(k);
-  if (it == h->key_index.end()) return fail(h, DHW_ERR_KEY, "unexpected key in MobileNetV2 state_dict: %s", key);
-  const SKey& s = h->spec[it->second];
-  bool ok = ndim == (int)s.shape.size();
-  size_t n = 1;
-  for (int i = 0; ok && i < ndim; ++i) { ok = shape[i] == s.shape[i]; n *= (size_t)s.shape[i]; }
-  if (!ok) return fail(h, DHW_ERR_KEY, "size mismatch for %s", key);
-  std::vector<float>& dst = h->host_w[it->second];
-  dst.resize(n);
-  switch (dtype) {
-    case DHW_F32: std::memcpy(dst.data(), host_ptr, n * 4); break;
-    case DHW_F64: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double*)host_ptr)[i]; break;
-    case DHW_BF16: for (size_t i = 0; i < n; ++i) dst[i] = bf2f(((const uint16_t*)host_ptr)[i]); break;
-    default: return fail(h, DHW_ERR_ARG, "dhw_style_load: unsupported dtype %d", dtype);
-  }
-  h->loaded[it->second] = 1;
-  h->packed = false;
-  return 0;
+  STYLE_GUARD(h, "dhw_style_load", int, {
+    if (!h || !key || !host_ptr || (!shape && ndim > 0)) return fail(h, DHW_ERR_ARG, "dhw_style_load: null argument");
+    const std::string k = key;
+    // the parts of torchvision's MobileNetV2 state_dict the feature extractor does not use
+    if (k.rfind("classifier.", 0) == 0 || (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0)) return 0;
+    auto it = h->key_index.find(k);
+    if (it == h->key_index.end()) return fail(h, DHW_ERR_KEY, "unexpected key in MobileNetV2 state_dict: %s", key);
+    const SKey& s = h->spec[it->second];
+    bool ok = ndim == (int)s.shape.size();
+    size_t n = 1;
+    for (int i = 0; ok && i < ndim; ++i) { ok = shape[i] == s.shape[i]; n *= (size_t)s.shape[i]; }
+    if (!ok) return fail(h, DHW_ERR_KEY, "size mismatch for %s", key);
+    std::vector<float>& dst = h->host_w[it->second];
+    dst.resize(n);
+    switch (dtype) {
+      case DHW_F32: std::memcpy(dst.data(), host_ptr, n * 4); break;
+      case DHW_F64: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double*)host_ptr)[i]; break;
+      case DHW_BF16: for (size_t i = 0; i < n; ++i) dst[i] = bf2f(((const uint16_t*)host_ptr)[i]); break;
+      default: return fail(h, DHW_ERR_ARG, "dhw_style_load: unsupported dtype %d", dtype);
+    }
+    h->loaded[it->second] = 1;
+    h->packed = false;
+    return 0;
+  });
 }
 
 int dhw_style_finalize(dhw_style* h) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  if (h->packed) return 0;
-  for (size_t i = 0; i < h->spec.size(); ++i)
-    if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in MobileNetV2 state_dict: %s", h->spec[i].key.c_str());
-  SHIP(h, hipSetDevice(h->device));
-  SHIP(h, hipDeviceSynchronize());
-  int rc;
-  {  // stem: the 3 input channels carry the same grey image -> sum the kernel over them
-    std::vector<float> sc, sh;
-    bn_affine(h, "features.0.1", kStem, sc, sh);
-    const auto& w = W(h, "features.0.0.weight");
-    const int cp = padc(kStem);
-    std::vector<float> wf((size_t)9 * cp, 0.f), bias(cp, 0.f);
-    for (int o = 0; o < kStem; ++o) {
-      for (int t = 0; t < 9; ++t) {
-        float s = 0.f;
-        for (int ci = 0; ci < 3; ++ci) s += w[((size_t)o * 3 + ci) * 9 + t];
-        wf[(size_t)t * cp + o] = s * sc[o];
+  STYLE_GUARD(h, "dhw_style_finalize", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    if (h->packed) return 0;
+    for (size_t i = 0; i < h->spec.size(); ++i)
+      if (!h->loaded[i]) return fail(h, DHW_ERR_KEY, "missing key in MobileNetV2 state_dict: %s", h->spec[i].key.c_str());
+    SHIP(h, hipSetDevice(h->device));
+    SHIP(h, hipDeviceSynchronize());
+    int rc;
+    {  // stem: the 3 input channels carry the same grey image -> sum the kernel over them
+      std::vector<float> sc, sh;
+      bn_affine(h, "features.0.1", kStem, sc, sh);
+      const auto& w = W(h, "features.0.0.weight");
+      const int cp = padc(kStem);
+      std::vector<float> wf((size_t)9 * cp, 0.f), bias(cp, 0.f);
+      for (int o = 0; o < kStem; ++o) {
+        for (int t = 0; t < 9; ++t) {
+          float s = 0.f;
+          for (int ci = 0; ci < 3; ++ci) s += w[((size_t)o * 3 + ci) * 9 + t];
+          wf[(size_t)t * cp + o] = s * sc[o];
+        }
+        bias[o] = sh[o];
       }
-      bias[o] = sh[o];
+      if ((rc = upload_f32(h, wf, &h->stem_w)) || (rc = upload_f32(h, bias, &h->stem_b))) return rc;
     }
-    if ((rc = upload_f32(h, wf, &h->stem_w)) || (rc = upload_f32(h, bias, &h->stem_b))) return rc;
-  }
-  h->blocks.clear();
-  for (const BlockDesc& d : block_descs()) {
-    dhw_style::Block b;
-    b.d = d;
-    b.cin_p = padc(d.cin);
-    b.hid_p = padc(d.hid);
-    b.cout_p = padc(d.cout);
-    const std::string p = "features." + std::to_string(d.idx) + ".conv.";
-    int j = 0;
-    if (d.t != 1) {
-      if ((rc = pack_pointwise(h, p + "0.0.weight", p + "0.1", d.hid, d.cin, b.hid_p, b.cin_p, &b.w_exp, &b.b_exp))) return rc;
-      j = 1;
+    h->blocks.clear();
+    for (const BlockDesc& d : block_descs()) {
+      dhw_style::Block b;
+      b.d = d;
+      b.cin_p = padc(d.cin);
+      b.hid_p = padc(d.hid);
+      b.cout_p = padc(d.cout);
+      const std::string p = "features." + std::to_string(d.idx) + ".conv.";
+      int j = 0;
+      if (d.t != 1) {
+        if ((rc = pack_pointwise(h, p + "0.0.weight", p + "0.1", d.hid, d.cin, b.hid_p, b.cin_p, &b.w_exp, &b.b_exp))) return rc;
+        j = 1;
+      }
+      if ((rc = pack_depthwise(h, p + std::to_string(j) + ".0.weight", p + std::to_string(j) + ".1", d.hid, b.hid_p, &b.w_dw, &b.b_dw))) return rc;
+      if ((rc = pack_pointwise(h, p + std::to_string(j + 1) + ".weight", p + std::to_string(j + 2), d.cout, d.hid, b.cout_p, b.hid_p, &b.w_proj, &b.b_proj))) return rc;
+      h->blocks.push_back(b);
     }
-    if ((rc = pack_depthwise(h, p + std::to_string(j) + ".0.weight", p + std::to_string(j) + ".1", d.hid, b.hid_p, &b.w_dw, &b.b_dw))) return rc;
-    if ((rc = pack_pointwise(h, p + std::to_string(j + 1) + ".weight", p + std::to_string(j + 2), d.cout, d.hid, b.cout_p, b.hid_p, &b.w_proj, &b.b_proj))) return rc;
-    h->blocks.push_back(b);
-  }
-  if ((rc = pack_pointwise(h, "features.18.0.weight", "features.18.1", kLast, 320, kLast, padc(320), &h->w_last, &h->b_last))) return rc;
-  h->packed = true;
-  return 0;
+    if ((rc = pack_pointwise(h, "features.18.0.weight", "features.18.1", kLast, 320, kLast, padc(320), &h->w_last, &h->b_last))) return rc;
+    if (h->lookup_fail) return DHW_ERR_INTERNAL;
+    h->packed = true;
+    return 0;
+  });
 }
 
 int dhw_style_forward(dhw_style* h, const float* img, int B, int H, int W, float* out, void* hip_stream) {
-  if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
-  if (!img || !out) return fail(h, DHW_ERR_ARG, "dhw_style_forward: null pointer");
-  if (B < 1 || H < 96 || W < 96) return fail(h, DHW_ERR_ARG, "dhw_style_forward: needs B >= 1 and an image of at least 96 x 96 (got %d x %d x %d)", B, H, W);
-  int rc = dhw_style_finalize(h);
-  if (rc) return rc;
-  SHIP(h, hipSetDevice(h->device));
-  if ((rc = ensure_buffers(h, B, H, W))) return rc;
-  hipStream_t st = (hipStream_t)hip_stream;
-  int hh = (H + 1) / 2, ww = (W + 1) / 2, cur = 0;
-  hipError_t e = launch_style_stem(h->prec, img, B, H, W, h->stem_w, h->stem_b, padc(kStem), h->buf[0], st);
-  if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "stem: %s", hipGetErrorString(e));
-  for (const dhw_style::Block& b : h->blocks) {
-    const int a = (cur + 1) % 3, c = (cur + 2) % 3;
-    const void* hidden = h->buf[cur];
-    if (b.d.t != 1) {
-      if ((rc = run_pointwise(h, h->buf[cur], B, (long)hh * ww, b.cin_p, b.hid_p, b.w_exp, b.b_exp, true, nullptr, h->buf[a], st))) return rc;
-      hidden = h->buf[a];
+  STYLE_GUARD(h, "dhw_style_forward", int, {
+    if (!h) return fail(nullptr, DHW_ERR_ARG, "null handle");
+    if (!img || !out) return fail(h, DHW_ERR_ARG, "dhw_style_forward: null pointer");
+    if (B < 1 || H < 96 || W < 96) return fail(h, DHW_ERR_ARG, "dhw_style_forward: needs B >= 1 and an image of at least 96 x 96 (got %d x %d x %d)", B, H, W);
+    int rc = dhw_style_finalize(h);
+    if (rc) return rc;
+    SHIP(h, hipSetDevice(h->device));
+    if ((rc = ensure_buffers(h, B, H, W))) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    int hh = (H + 1) / 2, ww = (W + 1) / 2, cur = 0;
+    hipError_t e = launch_style_stem(h->prec, img, B, H, W, h->stem_w, h->stem_b, padc(kStem), h->buf[0], st);
+    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "stem: %s", hipGetErrorString(e));
+    for (const dhw_style::Block& b : h->blocks) {
+      const int a = (cur + 1) % 3, c = (cur + 2) % 3;
+      const void* hidden = h->buf[cur];
+      if (b.d.t != 1) {
+        if ((rc = run_pointwise(h, h->buf[cur], B, (long)hh * ww, b.cin_p, b.hid_p, b.w_exp, b.b_exp, true, nullptr, h->buf[a], st))) return rc;
+        hidden = h->buf[a];
+      }
+      const int ho = b.d.stride == 2 ? (hh + 1) / 2 : hh, wo = b.d.stride == 2 ? (ww + 1) / 2 : ww;
+      e = launch_style_dw(h->prec, hidden, B, hh, ww, b.d.stride, b.w_dw, b.b_dw, b.hid_p, h->buf[c], st);
+      if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "depthwise %d: %s", b.d.idx, hipGetErrorString(e));
+      // projection (no activation) + the residual when the block keeps shape; written over the dead expanded map
+      if ((rc = run_pointwise(h, h->buf[c], B, (long)ho * wo, b.hid_p, b.cout_p, b.w_proj, b.b_proj, false, b.d.res ? h->buf[cur] : nullptr, h->buf[a], st)))
+        return rc;
+      cur = a;
+      hh = ho;
+      ww = wo;
     }
-    const int ho = b.d.stride == 2 ? (hh + 1) / 2 : hh, wo = b.d.stride == 2 ? (ww + 1) / 2 : ww;
-    e = launch_style_dw(h->prec, hidden, B, hh, ww, b.d.stride, b.w_dw, b.b_dw, b.hid_p, h->buf[c], st);
-    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "depthwise %d: %s", b.d.idx, hipGetErrorString(e));
-    // projection (no activation) + the residual when the block keeps shape; written over the dead expanded map
-    if ((rc = run_pointwise(h, h->buf[c], B, (long)ho * wo, b.hid_p, b.cout_p, b.w_proj, b.b_proj, false, b.d.res ? h->buf[cur] : nullptr, h->buf[a], st)))
-      return rc;
-    cur = a;
-    hh = ho;
-    ww = wo;
-  }
-  const int nxt = (cur + 1) % 3;
-  if ((rc = run_pointwise(h, h->buf[cur], B, (long)hh * ww, padc(320), kLast, h->w_last, h->b_last, true, nullptr, h->buf[nxt], st))) return rc;
-  h->feat = h->buf[nxt];
-  h->fB = B; h->fH = hh; h->fW = ww;
-  e = launch_style_pool(h->prec, h->buf[nxt], B, hh, ww, kLast, kBins, out, st);
-  if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "pool: %s", hipGetErrorString(e));
-  return 0;
+    const int nxt = (cur + 1) % 3;
+    if ((rc = run_pointwise(h, h->buf[cur], B, (long)hh * ww, padc(320), kLast, h->w_last, h->b_last, true, nullptr, h->buf[nxt], st))) return rc;
+    h->feat = h->buf[nxt];
+    h->fB = B; h->fH = hh; h->fW = ww;
+    e = launch_style_pool(h->prec, h->buf[nxt], B, hh, ww, kLast, kBins, out, st);
+    if (e != hipSuccess) return fail(h, DHW_ERR_HIP, "pool: %s", hipGetErrorString(e));
+    return 0;
+  });
 }
 
 int64_t dhw_style_debug_features(dhw_style* h, float* host_dst, int64_t max_floats, int64_t shape_out[4]) {
-  if (!h || !host_dst || !h->feat) return fail(h, DHW_ERR_ARG, "dhw_style_debug_features: no forward yet");
-  const int64_t n = (int64_t)h->fB * h->fH * h->fW * kLast;
-  if (n > max_floats) return fail(h, DHW_ERR_ARG, "buffer too small");
-  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(h, DHW_ERR_HIP, "sync failed");
-  if (shape_out) { shape_out[0] = h->fB; shape_out[1] = h->fH; shape_out[2] = h->fW; shape_out[3] = kLast; }
-  if (h->prec == PREC_F32) {
-    if (hipMemcpy(host_dst, h->feat, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
-  } else {
-    std::vector<uint16_t> tmp(n);
-    if (hipMemcpy(tmp.data(), h->feat, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
-    for (int64_t i = 0; i < n; ++i) host_dst[i] = bf2f(tmp[i]);
-  }
-  return n;
+  STYLE_GUARD(h, "dhw_style_debug_features", int64_t, {
+    if (!h || !host_dst || !h->feat) return fail(h, DHW_ERR_ARG, "dhw_style_debug_features: no forward yet");
+    const int64_t n = (int64_t)h->fB * h->fH * h->fW * kLast;
+    if (n > max_floats) return fail(h, DHW_ERR_ARG, "buffer too small");
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(h, DHW_ERR_HIP, "sync failed");
+    if (shape_out) { shape_out[0] = h->fB; shape_out[1] = h->fH; shape_out[2] = h->fW; shape_out[3] = kLast; }
+    if (h->prec == PREC_F32) {
+      if (hipMemcpy(host_dst, h->feat, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+    } else {
+      std::vector<uint16_t> tmp(n);
+      if (hipMemcpy(tmp.data(), h->feat, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DHW_ERR_HIP, "memcpy failed");
+      for (int64_t i = 0; i < n; ++i) host_dst[i] = bf2f(tmp[i]);
+    }
+    return n;
+  });
 }
 
 }  // extern "C"

@@ -62,8 +62,16 @@ class _DifferentiableForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, strokes, text, sigma, style, *params):
         tm = model._trainer
-        score, pen = tm.forward(strokes, text.to("cpu"), sigma.reshape(strokes.shape[0], 1), style)
         model._train_generation += 1
+        if tm.drop_rate > 0.0:
+            # A fresh Philox draw index per differentiable forward (and per data-parallel rank), as train_step / GraphedTrainStep set
+            # one per update: the EncoderLayers' keep-masks are keyed by (seed, draw index, sample, site), and the reference draws a
+            # fresh mask in every call (model.py:23 nn.Dropout).  Without this every train-mode call replayed draw 0's masks.
+            dist = torch.distributed
+            on = dist.is_available() and dist.is_initialized()
+            rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+            tm.rng.copy_(torch.tensor([tm.seed, model._train_generation * world + rank], dtype=torch.int64))
+        score, pen = tm.forward(strokes, text.to("cpu"), sigma.reshape(strokes.shape[0], 1), style)
         ctx.model, ctx.generation = model, model._train_generation
         return score.clone(), pen.clone()
 

@@ -18,7 +18,9 @@
  *
  * Conventions: plain pointers and sizes only (no torch types).  Every function
  * returns 0 on success or a negative dhw_status; nothing throws across the
- * ABI.  All tensor arguments of dhw_forward / dhw_sample are DEVICE pointers to
+ * ABI: every entry point of this library (dhw.h, dhw_debug.h, dhw_style.h,
+ * dhw_train.h) runs inside a catch-all barrier that turns a C++ exception into
+ * DHW_ERR_INTERNAL + a message (tests/test_host_cpu.py provokes one).  All tensor arguments of dhw_forward / dhw_sample are DEVICE pointers to
  * contiguous row-major buffers owned by the caller; work is enqueued on the
  * given HIP stream and is asynchronous w.r.t. the host.  The library owns its
  * packed weights, FiLM tables and workspace (sized at create from the dims).
@@ -42,7 +44,10 @@ typedef enum {
   DHW_ERR_ARG = -1,       /* bad argument / unsupported dims */
   DHW_ERR_KEY = -2,       /* unknown, duplicate or missing state_dict key, or shape mismatch */
   DHW_ERR_HIP = -3,       /* HIP runtime error (no device, launch failure, OOM) */
-  DHW_ERR_STATE = -4      /* call order (e.g. forward before all weights are loaded) */
+  DHW_ERR_STATE = -4,     /* call order (e.g. forward before all weights are loaded) */
+  DHW_ERR_INTERNAL = -5   /* a C++ exception (std::bad_alloc, std::out_of_range, ...) or an internal inconsistency inside the library:
+                             caught at the ABI (csrc/abi_guard.h), reported through dhw_last_error; the process and the handle stay
+                             alive (the failed call's outputs are undefined) */
 } dhw_status;
 
 /* dtype codes for dhw_load */

@@ -56,6 +56,11 @@ int dhw_debug_randn(dhw_handle*, uint64_t seed, int64_t first_sample, int B, int
  * [0, nwg) that gives each of the 8 XCDs a contiguous id range.  Host-side copy for tests; needs no device. */
 int dhw_debug_xcd_swizzle(int block_id, int nwg);
 
+/* Raise a C++ exception inside the guarded body of an entry point: kind 1 = std::out_of_range (a std::map::at miss), 2 =
+ * std::bad_alloc, 3 = a non-std exception.  Returns DHW_ERR_INTERNAL with the message in dhw_last_error(handle) — the test of
+ * "nothing throws across the ABI" (include/dhw.h).  Needs no device; the handle may be NULL (message in the global slot). */
+int dhw_debug_raise(dhw_handle*, int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,7 +108,9 @@ typedef struct {
   /* FiLM (+ SiLU) of the value written to C as a further output of the same pass (appended in round 4; film_out = NULL: none):
        film_out[m][n] = act(film_gamma[(m / film_rows) * film_pstride + n] * c + film_beta[...]) + film_addend[m][n]
      with c the value written to C, act = SiLU when film_act, film_addend NULL or laid out as C — a ConvBlock's
-     SiLU(affine(conv(.))) / affine3(fc(.)) + conv_skip(.) (cnn.py:70-86) without a pass of its own.  accumulate must be 0. */
+     SiLU(affine(conv(.))) / affine3(fc(.)) + conv_skip(.) (cnn.py:70-86) without a pass of its own.  accumulate must be 0, and the
+     GEMM must be UNBATCHED (nzo * nzi = 1: film_out / film_addend carry no batch offset) — a batched descriptor with film_out is
+     rejected with DHW_ERR_ARG by dhw_op_gemm / dhw_op_gemm2 / dhw_op_gemm_group. */
   const float* film_gamma; const float* film_beta; long long film_pstride; int film_rows; int film_act;
   float* film_out; const float* film_addend;
 } dhw_gemm_desc;

@@ -86,3 +86,28 @@ def test_train_mode_runs_with_dropout_and_survives_a_move():
     eps, pen, _ = m(x.cuda(), text.cuda(), sigma.cuda(), style.cuda())
     (eps.square().mean() + pen.mean()).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_train_mode_draws_fresh_dropout_masks_per_call_and_eval_mode_is_deterministic():
+    """reference model.py:23 / text_style.py:88: nn.Dropout draws a new mask in every train-mode call; eval mode is a function
+    of the inputs.  The EncoderLayer masks come from the device generator keyed by a per-call draw index, which the
+    differentiable forward has to advance itself (it is not a train_step)."""
+    sd, m, x, text, sigma, style, w1, w2 = _setup(seed=8)
+    m.train()
+    assert m.drop_rate > 0
+    # the style Dropout(0.3) mask is drawn on the host per call as well: pin torch's generator so that ONLY the EncoderLayer
+    # dropout (device generator) can differ between the two calls
+    torch.manual_seed(123)
+    a, pa, _ = m(x, text, sigma, style)
+    idx_a = int(m._trainer.rng[1])
+    torch.manual_seed(123)
+    b, pb, _ = m(x, text, sigma, style)
+    idx_b = int(m._trainer.rng[1])
+    assert idx_b == idx_a + 1
+    assert not torch.equal(a.detach(), b.detach()), "two train-mode forwards replayed the same EncoderLayer dropout masks"
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    m.eval()
+    m.requires_grad_(True)             # still the differentiable path (fp32 training kernels), dropout off
+    c, pc, _ = m(x, text, sigma, style)
+    d, pd, _ = m(x, text, sigma, style)
+    assert torch.equal(c.detach(), d.detach()) and torch.equal(pc.detach(), pd.detach())

@@ -290,6 +290,30 @@ def test_error_behaviour_mirrors_the_reference():
         l.dhw_destroy(h)
 
 
+def test_internal_errors_come_back_as_a_status_and_the_handle_survives():
+    """include/dhw.h "nothing throws across the ABI", on a live handle: an unknown activation name is an argument error with
+    the name in the message (round 4: a std::map::at on such a name aborted the process); an exception raised inside an entry
+    point's body is DHW_ERR_INTERNAL with the message on the handle; the handle computes the same forward afterwards."""
+    m = get_model(2, "fp32")
+    inp = spec.synthetic_inputs(2, 16, 3, seed=4)
+    args = [torch.from_numpy(inp[k]).cuda() for k in ("strokes", "text")] + [torch.full((2, 1), 0.6).cuda(), torch.from_numpy(inp["style"]).cuda()]
+    e0, p0, _ = m(*args)
+    l = _lib.lib()
+    buf = np.zeros(16, np.float32)
+    shape = (C.c_int64 * 3)()
+    for name in (b"enc3.k1", b"no.such.tap", b""):
+        rc = l.dhw_debug_read(m._handle, name, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, shape)
+        assert rc == -1 and b"no activation named" in l.dhw_last_error(m._handle), (name, rc)
+    with pytest.raises(_lib.DhwError):
+        m.debug_read("att_layers.7")
+    for kind, needle in ((1, b"map::at"), (2, b"bad_alloc"), (3, b"unknown C++ exception")):
+        assert l.dhw_debug_raise(m._handle, kind) == -5
+        assert needle in l.dhw_last_error(m._handle)
+    e1, p1, _ = m(*args)
+    assert torch.equal(e0, e1) and torch.equal(p0, p1)
+    assert m.debug_read("enc3").shape == (2, 8, 192)
+
+
 def test_cpu_inputs_are_moved_and_results_come_back_on_cpu():
     """Drop-in use as in the reference's own smoke test (tests/test_model.py:14-21): CPU tensors in, tensors out."""
     torch.manual_seed(0)

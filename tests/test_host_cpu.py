@@ -153,6 +153,39 @@ def test_create_rejects_bad_dims():
     assert l.dhw_create(None, None, 0) == -1
 
 
+def test_no_exception_crosses_the_c_abi():
+    """include/dhw.h: "nothing throws across the ABI".  Round 4's logs hold three host-process aborts from a std::out_of_range
+    (std::map::at on a workspace name) that left dhw_forward.  dhw_debug_raise throws INSIDE the guarded body of an entry point
+    — the same std::map::at miss, a std::bad_alloc, a non-std exception —: each must come back as DHW_ERR_INTERNAL (-5) with
+    a message, and this process must still be alive to assert it."""
+    l = _lib.lib()
+    for kind, needle in ((1, b"map::at"), (2, b"bad_alloc"), (3, b"unknown C++ exception")):
+        rc = l.dhw_debug_raise(None, kind)
+        assert rc == -5, (kind, rc)
+        msg = l.dhw_last_error(None)
+        assert b"dhw_debug_raise: internal error" in msg and needle in msg, msg
+    assert l.dhw_debug_raise(None, 99) == -1          # an ordinary argument error still reads as one
+    assert b"gfx950" in l.dhw_version()                # the library (and the interpreter) survived
+
+
+def test_every_entry_point_runs_behind_the_barrier():
+    """Structural: every extern "C" function with a multi-line body in the three API files opens with its file's *_GUARD macro
+    (csrc/abi_guard.h), so a new entry point cannot be added without the barrier."""
+    d = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd", "csrc")
+    total = 0
+    for f, guard in (("dhw_api.cpp", "DHW_GUARD("), ("dhw_style_api.cpp", "STYLE_GUARD("), ("dhw_train_api.cpp", "TRAIN_GUARD(")):
+        src = open(os.path.join(d, f)).read()
+        blocks = src.split('extern "C" {')[1:]
+        assert blocks, f
+        for blk in blocks:
+            blk = blk.split('}  // extern "C"')[0]
+            for m in re.finditer(r"^(?:int|int64_t) (dhw_\w+)\([^{;]*\{\n(.*?)^\}", blk, flags=re.S | re.M):
+                name, body = m.group(1), m.group(2)
+                assert body.lstrip().startswith(guard), f"{f}: {name} is not behind {guard}...)"
+                total += 1
+    assert total >= 50, total
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "diffusion-handwriting-generation.pytorch_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -11,7 +11,7 @@ run() {   # label, env...
   local label=$1; shift
   echo "== $label"
   env "$@" BENCH_ONLY=enc $R/tools/bin/bench_conv 50 2>&1 | grep "^enc1\|^enc2" | cut -c1-60
-  (cd /tmp && env "$@" rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY \
+  (cd /tmp && env "$@" timeout -k 10 240 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY \
       -d /tmp/tp_$$ --output-format csv -- $R/tools/bin/bench_conv 10 > /dev/null 2>&1)
   python3 - /tmp/tp_$$ <<'PY'
 import csv, glob, sys, collections
