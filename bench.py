@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the other-precision throughput figure (fp32_mode; bf16_mode with --train)")
+    ap.add_argument("--no-longseq", action="store_true", help="skip the configs[3] figure (longseq_mode: L=1000, T=1000, batch=32) in the default line")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short configs[4] training-step figure (train_step) in the default line")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="concurrent prompt sub-batches per GPU (0 = library default)")
@@ -274,10 +275,14 @@ def worker(args):
             res["model_tflops"] = fl * B * T * world * args.steps / dt / 1e12
             if not args.no_kernel_profile:
                 res["roofline"], res["kernels"] = kernel_profile(model, one_step, res["ms_per_step"])
+                # the attention stage on its own (244 keys at the L/2 level of this workload; 500 keys: longseq_mode below)
+                res["roofline"]["by_function"]["attention"] = attention_figure(model, dev, B, L, Lt)
             if world == 1 and not args.no_fp32 and args.precision == "bf16":
                 res["fp32_mode"] = other_mode(args, dev, text, style, precision="fp32", num_layers=args.num_layers)
                 if args.num_layers != 4:   # the class default depth (model.py:66; SURVEY 8: "report both, primary = 2")
                     res["nl4_mode"] = other_mode(args, dev, text, style, precision="bf16", num_layers=4)
+            if world == 1 and not args.no_longseq and args.precision == "bf16":
+                res["longseq_mode"] = longseq_mode(args, dev)
             if world == 1 and not args.no_train_step:
                 del model
                 torch.cuda.empty_cache()
@@ -563,6 +568,60 @@ def other_mode(args, dev, text, style, precision, num_layers):
     del m
     return {"value": B * L / dt, "unit": "stroke-points/s", "ms_per_step": dt * 1e3, "steps": n, "num_layers": num_layers, "precision": precision,
             "model_tflops": fl * B * T / dt / 1e12}
+
+
+def attention_figure(m, dev, B, L, Lt):
+    """north_star: "MFMA utilisation for attention against the chip's peak".  One denoiser call at (B, L, Lt), then the
+    self-attention stage (QK^T + softmax + PV + K/V staging inside enc_bc_kernel) of every stroke-side EncoderLayer timed on its
+    own by the library (dhw_debug_attention_time: the product kernel launched with and without the stage, HIP events)."""
+    import torch
+    from dhg_amd import spec
+    inp = spec.synthetic_inputs(B, L, Lt, seed=2, T=0)
+    with torch.no_grad():
+        m(torch.from_numpy(inp["strokes"]).to(dev), torch.from_numpy(inp["text"]).to(dev), torch.full((B, 1), 0.7, device=dev),
+          torch.from_numpy(inp["style"]).to(dev))
+    torch.cuda.synchronize(dev)
+    out = {}
+    for layer, (name, d, lk) in enumerate([("enc3", 192, L // 2), ("enc5", 256, L // 4)] + [(f"att_layers.{i}", 384, L // 8) for i in range(m.num_layers)]):
+        w, wo, fl = m.attention_time(layer, 20)
+        us = max(w - wo, 1e-3)
+        out[name] = {"keys": lk, "d": d, "heads": d // 64, "us": us, "enc_bc_us": w, "enc_bc_us_without_stage": wo, "flops": fl,
+                     "mfma_tflops": fl / us / 1e6, "mfma_frac": fl / us / 1e6 / PEAK_BF16_TFLOPS}
+    return out
+
+
+def longseq_mode(args, dev):
+    """BASELINE configs[3]: L=1000 strokes, T=1000 steps, batch=32 per GPU, Lt=62, bf16 (output_dense x 0.05 as in
+    tests/test_gpu_round2.py: a random-init free-running reverse process otherwise leaves fp32 range by step ~900, in the
+    reference's arithmetic too).  One warm-up (graph capture of the 1000-step loop) + 2 timed 1000-step batches; plus the
+    attention stage at this length (500 keys at the L/2 level)."""
+    import torch
+    import dhg_amd
+    from dhg_amd import spec
+    B, L, Lt, T = 32, 1000, 62, 1000
+    sd = {k: torch.from_numpy(v) for k, v in spec.synthetic_state_dict(args.num_layers).items()}
+    sd["output_dense.weight"] = sd["output_dense.weight"] * 0.05
+    sd["output_dense.bias"] = sd["output_dense.bias"] * 0.05
+    m = dhg_amd.DiffusionModel(args.num_layers, precision="bf16", max_B=B, max_L=L, max_Lt=Lt).eval()
+    m.load_state_dict(sd)
+    inp = spec.synthetic_inputs(B, L, Lt, seed=5, T=0)
+    tx, sv = torch.from_numpy(inp["text"]).to(dev), torch.from_numpy(inp["style"]).to(dev)
+    out = dhg_amd.sample(m, tx, sv, L=L, T=T, seed=3)
+    torch.cuda.synchronize(dev)
+    n = 2
+    t0 = time.perf_counter()
+    for k in range(n):
+        out = dhg_amd.sample(m, tx, sv, L=L, T=T, seed=4 + k)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    assert bool(torch.isfinite(out).all()), "non-finite samples (configs[3])"
+    fl, _ = m.work(L, Lt)
+    res = {"workload": f"configs[3]: batch={B}, T={T}, L={L}, Lt={Lt}, bf16, num_layers={args.num_layers}, output_dense x 0.05",
+           "value": B * L / dt, "unit": "stroke-points/s", "ms_per_step": dt * 1e3, "ms_per_denoiser_call": dt * 1e3 / T, "steps": n,
+           "model_tflops": fl * B * T / dt / 1e12, "model_mfma_frac": fl * B * T / dt / 1e12 / PEAK_BF16_TFLOPS,
+           "attention": attention_figure(m, dev, B, L, Lt)}
+    del m
+    return res
 
 
 def train_step_figure(args, dev):

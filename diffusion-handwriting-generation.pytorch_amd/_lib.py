@@ -73,6 +73,7 @@ SIGNATURES = {
     "dhw_debug_set_teacher": (C.c_int, [_P, _P, _P, C.c_int]),
     "dhw_debug_xcd_swizzle": (C.c_int, [C.c_int, C.c_int]),
     "dhw_debug_raise": (C.c_int, [_P, C.c_int]),
+    "dhw_debug_attention_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "dhw_set_streams": (C.c_int, [_P, C.c_int]),
     # include/dhw_style.h
     "dhw_style_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),

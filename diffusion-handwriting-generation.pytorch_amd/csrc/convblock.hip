@@ -21,7 +21,7 @@
 
 namespace {
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, int PP = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC * NW / 4, (OCC * NW / 4) < 2 ? 2 : OCC * NW / 4)))
 void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -31,10 +31,10 @@ void convblock_kernel(const ConvBlockParams p, const EncChain nx) {
   // are then handed from kernel to kernel inside one XCD's L2 (measured: a 98 KB tile written by the previous kernel on
   // the same XCD is read in 1.6 us, from another XCD in 3.8 us — tools/bench_handoff.cpp)
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-  convblock_body<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>(p, nx, bid / tiles, (bid % tiles) * BMO, smem);
+  convblock_body<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT, PP>(p, nx, bid / tiles, (bid % tiles) * BMO, smem);
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, int PP = 0>
 hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx = nullptr) {
   size_t lds = lds_bytes<T, BM, CO>(p.Cin, UPC ? p.up_cin : 0, TIGHT == 2 ? BM + 16 : BM);
   if (CH) lds = std::max(lds, (size_t)2 * BM * tile_stride<T>(CO) + 2 * 8 * BM * sizeof(float) + enc_a_text_kv_bytes<T, CO, BM>() + enc_a_param_bytes<T, CO>());
@@ -42,13 +42,13 @@ hipError_t launch_t(const ConvBlockParams& p, hipStream_t st, const EncChain* nx
   if (CIN && (p.Cin != CIN || (UPC && p.up_cin != up_skip_width<UPC>()))) return hipErrorInvalidValue;
   constexpr int BMO = TIGHT == 2 ? BM : BM - 2 - 2 * TIGHT;
   const int tiles = (p.L + BMO - 1) / BMO;
-  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
+  hipLaunchKernelGGL((convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT, PP>), dim3(p.B * tiles), dim3(NW * 64), lds, st, p, nx ? *nx : EncChain{});
   return hipGetLastError();
 }
 
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0>
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, int PP = 0>
 hipError_t attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(convblock_kernel<T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT, PP>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -70,6 +70,7 @@ hipError_t convblock_init() {
   A(bf16_t, 64, 128, 8, 1, 192, 0, 192); A(bf16_t, 128, 128, 8, 1, 192, 0, 192); A(bf16_t, 64, 192, 8, 1, 256, 0, 256);
   A(bf16_t, 64, 256, 8, 1, 384, 0, 384); A(bf16_t, 48, 256, 8, 1, 384, 0, 384);
   A(bf16_t, 128, 128, 8, 1, 192, 0, 192, 1); A(bf16_t, 48, 256, 8, 1, 384, 0, 384, 1);   // ... writing BM - 4 rows per tile (convblock_core.h, TIGHT)
+  A(bf16_t, 128, 128, 8, 1, 0, 0, 128, 0, 1); A(bf16_t, 128, 128, 8, 1, 192, 0, 192, 1, 1); A(bf16_t, 128, 128, 8, 1, 192, 0, 192, 0, 1);   // the tall tiles with the row halves one phase apart (PP)
   A(bf16_t, 32, 256, 8, 1, 0, 0, 192, 2); A(bf16_t, 32, 256, 8, 1, 384, 0, 384, 2);       // 32-row tiles of the widest blocks, conv1 over 48 rows (TIGHT = 2)
   // encoder blocks that continue into the next EncoderLayer's first half
   A(bf16_t, 64, 192, 8, 1, 0, 1, 128); A(bf16_t, 48, 256, 8, 1, 0, 1, 192); A(bf16_t, 64, 256, 8, 1, 0, 1, 192);
@@ -94,6 +95,13 @@ static bool use_asym32(const ConvBlockParams& p) {
   return t32 <= 256 && t32 > t46;
 }
 
+// DHW_CONV_PP: bit 0 = enc1-type tall tiles (126 rows x 128 channels), bit 1 = dec1-type (fused input stage), run with their row
+// halves one phase apart (convblock_core.h, PP).  Default: see the measurement in DESIGN 14.
+static int conv_pp() {   // (read per launch — capture time under graph replay — so that a test can flip it between two handles)
+  const char* e = getenv("DHW_CONV_PP");
+  return e ? atoi(e) : 0;
+}
+
 hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t st) {
   ConvBlockParams p = p_in;
   if (const char* e = getenv("DHW_CONV_STAGGER")) p.stagger = atoi(e);
@@ -106,6 +114,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
     auto tight = [&](int bm) { return tight_ok && (p.L + bm - 5) / (bm - 4) == (p.L + bm - 3) / (bm - 2); };
     if (p.Cout == 128 && p.Cin == 192 && p.up_cin == 128) {
       const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
+      if (big && (conv_pp() & 2)) return tight(128) ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 1, 1>(p, st) : launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 0, 1>(p, st);
       if (big && tight(128)) return launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 1>(p, st);
       return big ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192, 0, 192>(p, st);
     }
@@ -125,6 +134,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && sk && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 128, 8, 2, 0, 0, 128>(p, st);
+        if (sk && big && (conv_pp() & 1)) return launch_t<bf16_t, 128, 128, 8, 1, 0, 0, 128, 0, 1>(p, st);
         if (sk) return big ? launch_t<bf16_t, 128, 128, 8, 1, 0, 0, 128>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 0, 0, 128>(p, st);
         return big ? launch_t<bf16_t, 128, 128, 8>(p, st) : launch_t<bf16_t, 64, 128, 8>(p, st);
       }

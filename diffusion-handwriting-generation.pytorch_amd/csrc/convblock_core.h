@@ -68,7 +68,18 @@ template <int UPC> constexpr int up_skip_width() { return UPC == 384 ? 256 : UPC
 // 3-tap conv2 — runs over one more 16-row tile (BM + 16 rows, 2 of the extra 16 used), conv2 / fc / conv_skip over exactly BM.
 // For the L / 4 level of the bench shape (122 rows per sample): 4 tiles of 32 rows = 256 workgroups with 2 row tiles in three of
 // the four GEMM stages, instead of 3 tiles of 46 (44) rows = 192 workgroups with 3 row tiles in every stage and 64 idle CUs.
-template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, typename P, typename X>
+// PP = 1 ("ping-pong", round 5): the two row halves of the tile run ONE PHASE APART.  The 2 row-group x 4 channel-group layouts
+// of the tall tiles put waves w and w + 4 — same channels, lower / upper row half — on one SIMD, and in lockstep both are in
+// their MFMA main loop, then both in their VALU epilogue: the matrix pipe idles through every epilogue and the vector issue
+// through half of every main loop (SQ: MFMA busy 25 % of the kernel, VALU / MFMA co-execution 2-11 %).  With PP the upper half
+// (waves 4-7) leads by one phase: each stage is cut in two phases, main loop | epilogue, with a workgroup barrier after each, and
+// the lower half executes one extra barrier in front of its first phase (the upper half one behind its last) — the SAME
+// instruction stream, no role-specific code.  In every slot one wave of a SIMD issues MFMAs while its partner runs the previous
+// phase's bias + FiLM + SiLU + LDS stores.  Dependencies: conv2 of the lower half reads the upper half's first two h1 rows
+// (written two slots earlier: the upper half leads); nothing of the upper half reads the lower half's tiles; the bf16 output
+// tile overlays SiLU(x) only, which is dead once both halves have run conv1 (the fp32 tile of dec1 also overlays x: there the
+// upper half waits one slot in front of its output phase instead of behind it).
+template <typename T, int BM, int CO, int NW, int OCC = 1, int UPC = 0, int CH = 0, int CIN = 0, int TIGHT = 0, int PP = 0, typename P, typename X>
 DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, char* smem) {
   constexpr int ES = sizeof(T), NTHR = NW * 64;
   constexpr bool SK = CIN != 0;          // static contraction lengths
@@ -98,11 +109,16 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   static_assert(!ASYM || (CH == 0 && WM1 == 1), "the asymmetric tiling: plain blocks with one row group in conv1");
+  constexpr bool PPX = PP != 0;
+  static_assert(!PPX || (TALL && WM1 == 2 && WN1 == 4 && CH == 0 && !ASYM && OCC == 1), "ping-pong: the 2 x 4 wave layouts of the tall tiles");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
 
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int Cin = SK ? CIN : p.Cin;
+  // ping-pong: the upper row half (waves NW/2 ..) leads by one phase; a scalar, so the skew barriers sit in scalar branches
+  const bool pp_lead = PPX && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+#define PP_BARRIER() do { if constexpr (PPX) CB_BARRIER(); } while (0)
 
   const int SX = tile_stride<T>(Cin), SH1 = tile_stride<T>(C1), SH2 = h2_stride<T, BM>(CO);
   char* XS = smem;                       // SiLU(x)   [RX][Cin]
@@ -266,6 +282,15 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   }
   STAMP(15);
   CB_BARRIER();   // x tiles complete (and the staged skip rows, which overlay h1, consumed)
+  if constexpr (PPX) {
+    if (!pp_lead) {
+      // the trailing half idles through the leading half's first phase; it uses the slot to zero the two h1 rows past the computed
+      // ones (in lockstep every thread does that behind conv1's epilogue — here that would race with the leading half's conv2)
+      for (int id = tid; id < 2 * SH1 / 16; id += NTHR / 2)
+        *reinterpret_cast<uint4*>(H1 + BM1 * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
+      CB_BARRIER();
+    }
+  }
   STAMP(1);
 
   WRing<T, NT2, RING> ring2;
@@ -280,6 +305,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       else ring1.template run<MT1>(acc, XS + (row01 + l15) * SX + g * 8 * ES, SX, KCin);
     }
     STAMP(2);
+    PP_BARRIER();   // (ping-pong: main loop | epilogue are two slots)
     // epilogue of conv1, tile pair by tile pair, with the conv2 weight prefetch requested between the pairs
     constexpr int KT2 = (C1 / 32) * 3;
     const T* w2 = reinterpret_cast<const T*>(p.w_c2) + ((size_t)nt02 * KT2 * 64 + lane) * 8;
@@ -301,6 +327,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       for (int c = 0; c < CH2; ++c) ring2.template fill_chunk<KT2>(c);
     }
     // the two h1 rows past the computed BM (read only by the discarded output rows) must be finite
+    if constexpr (!PPX)
     for (int id = tid; id < 2 * SH1 / 16; id += NTHR)
       *reinterpret_cast<uint4*>(H1 + BM1 * SH1 + id * 16) = make_uint4(0, 0, 0, 0);
   }
@@ -314,6 +341,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
     acc_zero(acc);
     ring2.template run_s<MT2, (C1 / 32) * 3>(acc, H1 + (row02 + l15) * SH1 + g * 8 * ES, SH1, C1 / 32);
     STAMP(4);
+    PP_BARRIER();
     {
       constexpr int KTF = CO / 32;
       ring2.template fill_begin<KTF>(reinterpret_cast<const T*>(p.w_fc) + ((size_t)nt02 * KTF * 64 + lane) * 8);
@@ -350,6 +378,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   }
   STAMP(7);
   CB_BARRIER();   // every wave is done with the operand tiles: reuse LDS for the output tile
+  // (ping-pong: "every wave" = this half; the bf16 tile only overlays SiLU(x), dead since both halves' conv1.  The fp32 tile also
+  // overlays x, which the trailing half's conv_skip is reading in this slot: the leading half spends its extra slot HERE.)
+  if constexpr (PPX) { if (pp_lead && p.out_f32) CB_BARRIER(); }
   STAMP(8);
 
   const int rows_valid = min(BMO, p.L - m0);
@@ -363,6 +394,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
           store4(reinterpret_cast<float*>(smem + (row02 + j * 16 + l15) * SO) + n2 + 16 * i, acc[i][j] + ep2.bias[i]);
     }
     CB_BARRIER();
+    // (ping-pong, fp32 tile: both halves stored in the same slot — the leading half waited in front of it)
     if (p.out)
       tile_copy_out<float>(smem, SO, reinterpret_cast<float*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.fuse_heads) {
@@ -397,6 +429,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       store_tiles<T, NT2, MT2>(lane, smem, SH2, row02, n2, acc);
     }
     CB_BARRIER();
+    if constexpr (PPX) { if (pp_lead) CB_BARRIER(); }   // the trailing half stores its rows one slot later
     if constexpr (!(DHW_ABL & 16))
     tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.pool && !(DHW_ABL & 16))   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even

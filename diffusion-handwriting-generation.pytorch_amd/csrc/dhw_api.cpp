@@ -2051,6 +2051,55 @@ int dhw_debug_randn(dhw_handle* h, uint64_t seed, int64_t first_sample, int B, i
   });
 }
 
+// The self-attention stage of an EncoderLayer's second kernel on its own (bench.py, roofline.by_function.attention; north_star:
+// "MFMA utilisation for attention against the chip's peak").  enc_bc_kernel of layer `layer` (0 = enc3, 1 = enc5, 2.. = the
+// bottleneck layers) is launched `iters` times back to back WITH its attention stage and `iters` times with the stage skipped
+// (EncLayerParams.dbg bit 0, csrc/enc_bc_core.h) on the buffers the LAST dhw_forward(B, L, Lt) left in the workspace; the
+// difference of the two mean launch times (HIP events on the stream) is the time of QK^T + softmax + PV + K / V staging.
+// The product kernel, unmodified: no stamps, no extra instantiation.  flops_out = 4 B Lk^2 d (QK^T and PV over all heads).
+int dhw_debug_attention_time(dhw_handle* h, int layer, int iters, double* us_with, double* us_without, double* flops_out, void* hip_stream) {
+  DHW_GUARD(h, "dhw_debug_attention_time", int, {
+    if (!h || !us_with || !us_without || iters < 1 || layer < 0) return fail(h, DHW_ERR_ARG, "dhw_debug_attention_time: bad argument");
+    if (!h->packed || !h->last_B || layer >= (int)h->el.size()) return fail(h, DHW_ERR_STATE, "dhw_debug_attention_time: run dhw_forward first (layer %d of %d)", layer, (int)h->el.size());
+    const EncLayerW& w = h->el[layer];
+    if (!h->fuse || h->prec != PREC_BF16 || !enclayer_supported(h->prec, w.d, w.heads)) return fail(h, DHW_ERR_STATE, "dhw_debug_attention_time: the fused bf16 EncoderLayer kernels are not in use on this handle");
+    HIPCK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int B = h->last_B, L = h->last_L;
+    const int Lk = (int)el_rows(L, layer);
+    Ctx c{h, &h->ws[0], st, B, L, h->last_Lt, h->dims.S * 5, h->d_film, 2L * h->film_tot};
+    const void* x = layer == 0 ? CBB(c, CB_ENC2, out) : layer == 1 ? CBB(c, CB_ENC4, out) : layer == 2 ? WS(c, att_dense) : ELB(c, layer - 1, out);
+    EncLayerParams q = enc_params(c, layer, w, x, Lk, h->lpadX[layer < 2 ? layer : 2], h->d_text_stage, nullptr);
+    // (the measured launches write the layer's `out` again: same inputs, same values; with the stage skipped, different ones —
+    // the workspace is scratch between calls)
+    if (c.err) return c.err;
+    hipEvent_t e0, e1;
+    HIPCK(h, hipEventCreate(&e0));
+    HIPCK(h, hipEventCreate(&e1));
+    double us[2] = {0, 0};
+    int rc = 0;
+    for (int mode = 0; mode < 2 && !rc; ++mode) {
+      q.dbg = mode;   // 0: with the attention stage, 1: skipped
+      for (int it = 0; it < 3 + iters && !rc; ++it) {
+        if (it == 3 && hipEventRecord(e0, st) != hipSuccess) rc = fail(h, DHW_ERR_HIP, "event record failed");
+        hipError_t e = launch_enclayer(h->prec, q, 1, st, nullptr);
+        if (e != hipSuccess) rc = fail(h, DHW_ERR_HIP, "enc_bc launch: %s", hipGetErrorString(e));
+      }
+      float ms = 0.f;
+      if (!rc && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+        rc = fail(h, DHW_ERR_HIP, "event timing failed: %s", hipGetErrorString(hipGetLastError()));
+      us[mode] = (double)ms * 1e3 / iters;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc) return rc;
+    *us_with = us[0];
+    *us_without = us[1];
+    if (flops_out) *flops_out = 4.0 * B * (double)Lk * Lk * w.d;
+    return 0;
+  });
+}
+
 int dhw_profile_enable(dhw_handle* h, int on) {
   DHW_GUARD(h, "dhw_profile_enable", int, {
     if (!h) return DHW_ERR_ARG;

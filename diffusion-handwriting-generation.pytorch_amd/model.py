@@ -311,6 +311,14 @@ class DiffusionModel(nn.Module):
             out.append(dict(label=lab.value.decode(), total_ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value))
         return out
 
+    def attention_time(self, layer: int, iters: int = 20):
+        """(us with, us without, FLOPs) of EncoderLayer ``layer``'s self-attention stage on the last forward's activations
+        (include/dhw_debug.h dhw_debug_attention_time: the product's enc_bc_kernel with and without the stage)."""
+        a, b, fl = C.c_double(), C.c_double(), C.c_double()
+        st = torch.cuda.current_stream(self._handle_dev).cuda_stream
+        _lib.check(_lib.lib().dhw_debug_attention_time(self._handle, layer, iters, C.byref(a), C.byref(b), C.byref(fl), C.c_void_p(st)), self._handle)
+        return a.value, b.value, fl.value
+
     def work(self, L: int, Lt: int):
         """(FLOPs, block-boundary bytes) of one denoiser call per sample."""
         fl, by = C.c_double(), C.c_double()

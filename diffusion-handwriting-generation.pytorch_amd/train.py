@@ -122,6 +122,51 @@ def allreduce_grads(flat_grads, world_size: int | None = None, average: bool = T
     return flat_grads
 
 
+class GradBucketReducer:
+    """The data-parallel gradient all-reduce in BUCKETS, overlapped with the tail of the backward pass (reference: single
+    process, train.py:53-60 — nothing to mirror; BASELINE configs[4] / north_star: "RCCL grad all-reduce over xGMI").
+
+    ``flat_grad`` is the trainer's one flat gradient buffer, laid out in the ORDER IN WHICH THE BACKWARD SWEEP COMPLETES the
+    gradients (train_model.TrainModel orders it so: decoder + skip convolutions, bottleneck layers, encoder, text side + FiLM
+    Linears, sigma MLP), and ``ranges[i]`` = [start, end) of bucket i in it.  ``launch(i)`` is called the moment bucket i's last
+    weight-gradient kernel has been enqueued (eagerly: from the tape's bucket markers; under graph replay: after the graph segment
+    that ends at the marker): one asynchronous SUM all-reduce of that contiguous range.  With backend "nccl" (= RCCL) the
+    collective runs on the process group's own stream behind an event on the launching stream, i.e. beside the kernels the main
+    stream enqueues next — the rest of the backward; ``wait()`` makes the launching stream wait for all of them (and, for host-side
+    backends such as gloo, blocks until they are done).  1 / world size is left to the caller (Adam's grad_scale, or ``average``).
+
+    Bucket sizes (fp32, num_layers = 2): 6.4 / 12.2 / 6.9 / 11.3 / 0.3 MB — each a bandwidth-bound ring message on the per-link xGMI
+    rate; the last two cannot overlap with anything (the text side is the first thing in the forward, so its gradients are the last
+    to complete).  The 8-rank overlap itself is unmeasured here (one-GPU boxes): what is tested is that the bucketed result equals the
+    single flat all-reduce (2 ranks, gloo) and that every bucket's gradients are final when its marker fires (GPU test)."""
+
+    def __init__(self, flat_grad: torch.Tensor, ranges):
+        self.flat_grad, self.ranges = flat_grad, [tuple(r) for r in ranges]
+        if any(a >= b for a, b in self.ranges) or any(self.ranges[i][1] != self.ranges[i + 1][0] for i in range(len(self.ranges) - 1)) \
+                or self.ranges[0][0] != 0 or self.ranges[-1][1] != flat_grad.numel():
+            raise ValueError("bucket ranges must tile the flat gradient buffer in order")
+        self.works, self.launched = [], []
+
+    def launch(self, i: int):
+        import torch.distributed as dist
+        if i in self.launched:
+            raise RuntimeError(f"gradient bucket {i} reduced twice in one update")
+        a, b = self.ranges[i]
+        self.launched.append(i)
+        self.works.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self, average: bool = False, world_size: int | None = None):
+        import torch.distributed as dist
+        if sorted(self.launched) != list(range(len(self.ranges))):
+            raise RuntimeError(f"gradient buckets reduced this update: {sorted(self.launched)} of {len(self.ranges)}")
+        for w in self.works:
+            w.wait()
+        self.works, self.launched = [], []
+        if average:
+            self.flat_grad.div_(world_size or dist.get_world_size())
+        return self.flat_grad
+
+
 _CB_FIELDS = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "fc_w", "fc_b", "skip_w", "skip_b", "film_w", "film_b")
 
 

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .train import Adam, _stream, _tcheck, allreduce_grads, get_alphas, loss_fn, noam_lr, perturb
+from .train import Adam, GradBucketReducer, _stream, _tcheck, allreduce_grads, get_alphas, loss_fn, noam_lr, perturb
 
 _F = 4  # bytes per element
 
@@ -34,6 +34,33 @@ _F = 4  # bytes per element
 FUSE_DSILU = os.environ.get("DHW_TRAIN_FUSE_DSILU", "1") != "0"
 # DHW_TRAIN_FILM_RIDER=0: a ConvBlock's affine (+ SiLU) (+ conv_skip) as its own pass behind the GEMM again instead of a further output of the GEMM (A/B)
 FILM_RIDER = os.environ.get("DHW_TRAIN_FILM_RIDER", "1") != "0"
+# DHW_TRAIN_BUCKETS=0: one flat SUM all-reduce behind the whole backward (rounds 2-4) instead of bucketed all-reduces overlapped with its tail (A/B)
+GRAD_BUCKETS = os.environ.get("DHW_TRAIN_BUCKETS", "1") != "0"
+
+# Gradient buckets, in the order the backward sweep completes them (TrainModel lays the flat buffers out in this order, so a
+# bucket is ONE contiguous range = one all-reduce):
+#   0  decoder ConvBlocks + skip convolutions          final once the sweep is back at the end of the bottleneck layers
+#   1  bottleneck EncoderLayers + att_dense            ... at the end of enc5
+#   2  encoder ConvBlocks / EncoderLayers + input_dense ... in front of input_dense
+#   3  text side (TextStyleEncoder, every layer's text_dense: evaluated once, first, for all layers) + all FiLM Linears (their
+#      gradient is ONE kernel over the whole [B, 2 x 9280] table, the last but two of the sweep)
+#   4  sigma MLP (the first module of the forward) + the two heads' odd-sized tensors (kept last so that every other tensor starts
+#      16-byte aligned: the GEMMs take the 16-byte-load forms and film_table reads weight rows as f32x4)
+N_BUCKETS = 5
+
+
+def grad_bucket(name: str) -> int:
+    if name.startswith(("sigma_ffn.", "output_dense.", "pen_lifts_dense.")):
+        return 4
+    if ".gamma_emb." in name or ".beta_emb." in name or name.startswith("text_style_model.") or ".text_dense." in name:
+        return 3
+    if name.startswith(("dec1.", "dec2.", "dec3.", "skip_conv")):
+        return 0
+    if name.startswith(("att_layers.", "att_dense.")):
+        return 1
+    if name.startswith(("enc1.", "enc2.", "enc3.", "enc4.", "enc5.", "input_dense.")):
+        return 2
+    raise ValueError(f"no gradient bucket rule for parameter {name}")
 
 class Var:
     """A node of the tape: a device tensor and its lazily allocated (zero-initialised) gradient.  ``leaf``: a network input
@@ -539,6 +566,11 @@ class Tape:
             step()
         self.steps = []
 
+    def mark(self, fn):
+        """A position of the forward: ``fn`` runs when the backward sweep comes back to it, i.e. when every backward kernel of the ops
+        recorded AFTER this point has been enqueued (the gradient-bucket markers)."""
+        self.steps.append(fn)
+
     def record(self, out: Var, fn):
         """fn runs in the backward sweep iff a gradient reached ``out``."""
         self.steps.append(lambda: fn() if out.g is not None else None)
@@ -580,11 +612,25 @@ class TrainModel:
             h = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).detach().to("cpu", torch.float32)
             host[k] = (h.permute(2, 0, 1).contiguous() if k in conv_w else h).reshape(-1)
         # ONE flat fp32 buffer for all parameters and one for all gradients (40 MB each): a single memset clears the
-        # gradients, a single kernel pair clips and applies Adam, a single all-reduce averages them across ranks.
-        self.flat = torch.cat([host[k] for k in self.names]).to(self.dev)
+        # gradients, a single kernel pair clips and applies Adam.  The tensors sit in it in the order the backward sweep COMPLETES
+        # their gradients (grad_bucket; state_dict order inside a bucket, odd-sized tensors last), so each of the N_BUCKETS
+        # gradient buckets is one contiguous range that can be all-reduced the moment its marker fires (GradBucketReducer).
+        # self.names / state_dict() stay in the reference's order: the layout is private to the flat buffers.
+        self.layout = sorted(self.names, key=lambda k: (grad_bucket(k), host[k].numel() % 4 != 0))   # (stable: state_dict order otherwise)
+        self.flat = torch.cat([host[k] for k in self.layout]).to(self.dev)
         self.flat_grad = torch.zeros_like(self.flat)
         self.p, self.offset, off = {}, {}, 0
-        for k in self.names:
+        self.bucket_ranges, self.bucket_hook = [], None     # [start, end) of each bucket; bucket_hook(i): called when bucket i < N_BUCKETS - 1 is final
+        for b in range(N_BUCKETS):
+            n_b = sum(host[k].numel() for k in self.layout if grad_bucket(k) == b)
+            start = self.bucket_ranges[-1][1] if self.bucket_ranges else 0
+            self.bucket_ranges.append((start, start + n_b))
+        run = 0
+        for k in self.layout:
+            if run % 4 and host[k].numel() % 4 == 0:
+                raise ValueError(f"parameter {k} would start unaligned in the flat buffer (an odd-sized tensor precedes it)")
+            run += host[k].numel()
+        for k in self.layout:
             n = host[k].numel()
             view = (lambda buf: buf[off:off + n].view(3, *shapes[k][:2]).permute(1, 2, 0)) if k in conv_w else (lambda buf: buf[off:off + n].view(shapes[k]))
             v = Var(view(self.flat))
@@ -779,21 +825,25 @@ class TrainModel:
         x_in, sig_in, sty = Var(strokes.view(B * L, 2), leaf=True), Var(sigma.view(B, 1), leaf=True), Var(style, leaf=True)
 
         sigma_v = self._ffn(t, sig_in, "sigma_ffn")                                     # [B, 32]
+        t.mark(lambda: self._bucket_done(3))       # the sweep is back here: text side, text_dense and the FiLM table are done
         self._film_table(t, sigma_v, B)
         txt = t.silu(self._text_style(t, ids, sty, sigma_v, keep, B))                  # SiLU([B*Lt, 2 c2]): every EncoderLayer's text_dense starts
                                                                                        # with it (model.py:38) — once, not once per layer
         # every EncoderLayer's text_dense (model.py:38) reads the same SiLU(text features): one launch for all of them
         enc_names = ["enc3", "enc5"] + [f"att_layers.{i}" for i in range(self.num_layers)]
         td = dict(zip(enc_names, t.linear_group([(txt, self.p[n + ".text_dense.weight"], self.p[n + ".text_dense.bias"]) for n in enc_names])))
+        t.mark(lambda: self._bucket_done(2))       # ... encoder + input_dense done
         x, xa = self._lin(t, x_in, "input_dense", silu_out=True)
         h1 = self._convblock(t, x, sigma_v, "enc1", B, L, x_act=xa)
         h2 = self._convblock(t, t.resample(0, h1), sigma_v, "enc2", B, L // 2)
         h2 = self._encoder(t, h2, txt, sigma_v, mask, "enc3", B, 3, 4, td=td["enc3"])
         h3 = self._convblock(t, t.resample(0, h2), sigma_v, "enc4", B, L // 4)
         h3 = self._encoder(t, h3, txt, sigma_v, mask, "enc5", B, 4, 2, td=td["enc5"])
+        t.mark(lambda: self._bucket_done(1))       # ... att_dense + bottleneck layers done
         x = self._lin(t, t.resample(0, h3), "att_dense")
         for i in range(self.num_layers):
             x = self._encoder(t, x, txt, sigma_v, mask, f"att_layers.{i}", B, 6, 1, td=td[f"att_layers.{i}"])
+        t.mark(lambda: self._bucket_done(0))       # ... decoder + skip convolutions done
         # upsample(x) + skip_conv(h): the add rides on the skip convolution's output pass
         # (and SiLU of the sum, which the decoder block's conv1 starts with, is its second output)
         skip = lambda v, n, Lr, up: t.conv3(v, self.p[n + ".weight"], self.p[n + ".bias"], Lr, addend=up, silu_out=True)   # noqa: E731
@@ -807,8 +857,13 @@ class TrainModel:
         self._pen = t.sigmoid(self._lin(t, x, "pen_lifts_dense.0"))
         return self._score.d.view(B, L, 2), self._pen.d.view(B, L)
 
+    def _bucket_done(self, i: int):
+        if self.bucket_hook is not None:
+            self.bucket_hook(i)
+
     def backward(self, d_score: torch.Tensor, d_pen: torch.Tensor):
-        """Accumulate every parameter gradient for the upstream gradients of the two outputs."""
+        """Accumulate every parameter gradient for the upstream gradients of the two outputs.  ``self.bucket_hook(i)`` (if set) is
+        called from inside the sweep as soon as gradient bucket i = 0 .. N_BUCKETS - 2 is final; the last bucket is final on return."""
         self._score.g = d_score.contiguous().view_as(self._score.d)
         self._pen.g = d_pen.contiguous().view_as(self._pen.d)
         self.tape.backward()
@@ -853,9 +908,18 @@ def train_step(model: TrainModel, optimizer: Adam, batch: dict, alpha_set: torch
     model.rng.copy_(torch.tensor([model.seed, step * world + rank], dtype=torch.int64))
     score, pen_pred = model.forward(x_pert, batch["text"], torch.sqrt(alphas), batch["style"], style_keep, drop_masks)
     out, d_score, d_pen = loss_fn(eps, score, pen, pen_pred, alphas)
-    model.backward(d_score, d_pen)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()   # (also a one-rank group: the same code path)
+    reducer = GradBucketReducer(model.flat_grad, model.bucket_ranges) if dist_on and GRAD_BUCKETS else None
+    model.bucket_hook = reducer.launch if reducer else None
+    try:
+        model.backward(d_score, d_pen)
+    finally:
+        model.bucket_hook = None
     grads = model.grads()
-    if torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
+    if reducer:
+        reducer.launch(N_BUCKETS - 1)
+        reducer.wait(average=True)
+    elif dist_on:
         allreduce_grads(grads)
     model.last_grad_norm = float(optimizer.step(grads, noam_lr(step, d_model, warmup, lr_mul)))   # (one host sync per update)
     return out
@@ -908,6 +972,7 @@ class GraphedTrainStep:
         self.sqnorm, self.out = z(1), z(3)
         model.prepare_tables(L, Lt)
         self.graph = None
+        self.segments, self._reducer = None, None     # with a process group: N_BUCKETS graph segments + the bucketed all-reduce
         self._opt_in_graph = False
 
     def _body(self):
@@ -928,13 +993,54 @@ class GraphedTrainStep:
                                    self.out.data_ptr(), d_score.data_ptr(), d_pen.data_ptr(), st))
         m.backward(d_score, d_pen)
 
-    def _apply(self):
-        """Gradient averaging across ranks (one all-reduce of the flat 40 MB buffer: RCCL over xGMI) and the optimizer: three
-        launches, issued eagerly after the graph so that the collective stays outside the capture."""
+    def _apply(self, reducer=None):
+        """The optimizer behind the gradient all-reduce.  ``reducer``: the update's bucketed all-reduces are already in flight
+        (GradBucketReducer: launched bucket by bucket while the backward was still running) — wait for them; without one
+        (DHW_TRAIN_BUCKETS=0) ONE SUM all-reduce of the flat 40 MB buffer, issued here, behind the whole backward.  Adam applies
+        1 / world size (hyper[8]) in its own pass either way; the collectives stay outside the captured graphs."""
         m = self.model
-        if torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
-            allreduce_grads(m.grads(), average=False)      # SUM; Adam applies 1 / world size (hyper[8]) in its own pass
+        if reducer is not None:
+            reducer.launch(N_BUCKETS - 1)
+            reducer.wait()
+        elif torch.distributed.is_available() and torch.distributed.is_initialized():   # (also a one-rank group: the same code path)
+            allreduce_grads(m.grads(), average=False)
         self.opt.step_dev(m.grads(), self.hyper, self.sqnorm)
+
+    def _capture_segments(self):
+        """With a process group the update is captured as N_BUCKETS graph SEGMENTS cut at the tape's bucket markers (one shared
+        memory pool, replayed in capture order): after segment i has been enqueued, gradient bucket i is final and its all-reduce is
+        issued beside segment i + 1."""
+        import gc
+        m = self.model
+        gc.collect()
+        torch.cuda.synchronize(m.dev)
+        segs = []
+        side = torch.cuda.Stream(device=m.dev)
+        side.wait_stream(torch.cuda.current_stream(m.dev))
+        with torch.cuda.stream(side):
+            cur = torch.cuda.CUDAGraph()
+            cur.capture_begin()
+            state = {"cur": cur}
+
+            def cut(i):
+                state["cur"].capture_end()
+                segs.append(state["cur"])
+                if i != len(segs) - 1:
+                    raise RuntimeError(f"gradient bucket markers fired out of order: {i} after {len(segs) - 1} segments")
+                nxt = torch.cuda.CUDAGraph()
+                nxt.capture_begin(pool=segs[0].pool())
+                state["cur"] = nxt
+            m.bucket_hook = cut
+            try:
+                self._body()
+            finally:
+                m.bucket_hook = None
+                state["cur"].capture_end()
+            segs.append(state["cur"])
+        torch.cuda.current_stream(m.dev).wait_stream(side)
+        if len(segs) != N_BUCKETS:
+            raise RuntimeError(f"captured {len(segs)} graph segments for {N_BUCKETS} gradient buckets")
+        return segs
 
     def __call__(self, batch: dict, alpha_set, step: int, *, eps=None, alphas=None, style_keep=None, graph: bool = True):
         B, L, Lt, S = self.shape
@@ -971,9 +1077,27 @@ class GraphedTrainStep:
         ev = self._stage_ev[turn] = self._stage_ev[turn] or torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.model.dev))
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        bucketed = dist_on and GRAD_BUCKETS
+        if bucketed and self._reducer is None:
+            self._reducer = GradBucketReducer(self.model.flat_grad, self.model.bucket_ranges)
         if not graph:
-            self._body()
-            self._apply()
+            self.model.bucket_hook = self._reducer.launch if bucketed else None
+            try:
+                self._body()
+            finally:
+                self.model.bucket_hook = None
+            self._apply(self._reducer if bucketed else None)
+            return self.out
+        if bucketed:
+            if self.graph is not None:
+                raise RuntimeError("this step was captured without a process group; build a new GraphedTrainStep after init_process_group")
+            if self.segments is None:
+                self.segments = self._capture_segments()
+            for i, g in enumerate(self.segments):
+                g.replay()
+                if i < N_BUCKETS - 1:
+                    self._reducer.launch(i)       # bucket i is final behind segment i: its all-reduce runs beside segment i + 1
+            self._apply(self._reducer)
             return self.out
         if self.graph is None:
             # loss_kernel accumulates into out[1], out[2] — dhw_train_loss zeroes them itself; capture on torch's capture stream.

@@ -56,6 +56,13 @@ int dhw_debug_randn(dhw_handle*, uint64_t seed, int64_t first_sample, int B, int
  * [0, nwg) that gives each of the 8 XCDs a contiguous id range.  Host-side copy for tests; needs no device. */
 int dhw_debug_xcd_swizzle(int block_id, int nwg);
 
+/* The self-attention stage of EncoderLayer `layer` (0 = enc3, 1 = enc5, 2 + i = att_layers.i) timed on its own, on the
+ * activations the last dhw_forward left in the workspace: enc_bc_kernel launched `iters` times with the stage and `iters`
+ * times with the stage skipped, mean launch time of each in microseconds (HIP events on `hip_stream`); flops_out = the
+ * stage's QK^T + PV FLOPs, 4 B Lk^2 d.  bf16 handles with the fused kernels only; synchronises the stream. */
+int dhw_debug_attention_time(dhw_handle*, int layer, int iters, double* us_with, double* us_without, double* flops_out,
+                             void* hip_stream);
+
 /* Raise a C++ exception inside the guarded body of an entry point: kind 1 = std::out_of_range (a std::map::at miss), 2 =
  * std::bad_alloc, 3 = a non-std exception.  Returns DHW_ERR_INTERNAL with the message in dhw_last_error(handle) — the test of
  * "nothing throws across the ABI" (include/dhw.h).  Needs no device; the handle may be NULL (message in the global slot). */

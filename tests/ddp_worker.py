@@ -1,6 +1,6 @@
 """Helper of test_gpu_train_model.py::test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch: one rank of a
 data-parallel training run on a SHARED GPU (gloo rendezvous on 127.0.0.1; the gradient all-reduce is the product's
-``allreduce_grads``).  Each rank takes its slice of one seeded global batch; rank 0 writes the parameters after two updates."""
+bucketed ``GradBucketReducer`` behind the graph segments of ``GraphedTrainStep``; DHW_TRAIN_BUCKETS=0: the flat ``allreduce_grads``).  Each rank takes its slice of one seeded global batch; rank 0 writes the parameters after two updates."""
 import os
 import sys
 
@@ -38,7 +38,9 @@ def main():
         losses.append(step(batch, None, k, eps=eps[sl], alphas=alphas[sl], style_keep=keep[k - 1, sl]).cpu().numpy())
     torch.cuda.synchronize()
     if rank == 0:
-        np.savez(out, flat=model.flat.cpu().numpy(), losses=np.array(losses))
+        # (the parameters in state_dict order and torch layouts: the flat buffer's own order is the gradient buckets', private to the trainer)
+        flat = torch.cat([v.detach().contiguous().reshape(-1) for v in model.state_dict().values()])
+        np.savez(out, flat=flat.cpu().numpy(), losses=np.array(losses), segments=0 if step.segments is None else len(step.segments))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

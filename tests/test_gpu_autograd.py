@@ -110,4 +110,6 @@ def test_train_mode_draws_fresh_dropout_masks_per_call_and_eval_mode_is_determin
     m.requires_grad_(True)             # still the differentiable path (fp32 training kernels), dropout off
     c, pc, _ = m(x, text, sigma, style)
     d, pd, _ = m(x, text, sigma, style)
-    assert torch.equal(c.detach(), d.detach()) and torch.equal(pc.detach(), pd.detach())
+    # (the training kernels' split-K GEMMs accumulate with fp32 atomics: two runs agree to rounding level, not bit for bit)
+    assert torch.allclose(c.detach(), d.detach(), rtol=1e-5, atol=1e-6) and torch.allclose(pc.detach(), pd.detach(), rtol=1e-5, atol=1e-6)
+    assert (a.detach() - b.detach()).abs().max() > 100 * (c.detach() - d.detach()).abs().max()     # dropout changes values, not just their last bit

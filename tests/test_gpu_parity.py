@@ -395,6 +395,28 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
 
 
+def test_convblock_row_halves_one_phase_apart_give_the_same_bits():
+    """DHW_CONV_PP (csrc/convblock_core.h, PP): the tall 126-row ConvBlock tiles (enc1, dec1 once the batch needs them: B x ceil(L / 62)
+    > 256 workgroups) with their two row halves running one phase apart.  Only the barrier schedule changes — every MFMA and every
+    epilogue operation is the same instruction on the same operands — so the samples must be identical bit for bit, for each of
+    the two kinds of block on its own and for both."""
+    B, L, Lt, T = 66, 256, 9, 3
+    inp = spec.synthetic_inputs(B, L, Lt, seed=14, pad=1, T=T)
+    tx, sv, nz = (torch.from_numpy(inp[k]).cuda() for k in ("text", "style", "noise"))
+    outs = {}
+    for pp in ("0", "1", "2", "3"):
+        m = _fresh_model("bf16", {"DHW_CONV_PP": pp}, B=B, L=L, Lt=Lt)
+        os.environ["DHW_CONV_PP"] = pp          # (read at launch = graph capture time)
+        try:
+            outs[pp] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
+        finally:
+            os.environ.pop("DHW_CONV_PP", None)
+        del m
+    assert torch.isfinite(outs["0"]).all()
+    for pp in ("1", "2", "3"):
+        assert torch.equal(outs["0"], outs[pp]), f"DHW_CONV_PP={pp}"
+
+
 def test_two_text_pairs_per_workgroup_give_the_same_bits():
     """text_layer_kernel holds two (step, prompt) pairs of the all-steps text plane per workgroup when they share a FiLM row (even
     batch): one weight stream for both.  Same MFMA sequence per row => identical samples; forced on here (the launcher's own choice

@@ -386,9 +386,10 @@ def test_device_draws_are_standard_normal_and_drop_30_percent():
 
 def test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch(tmp_path):
     """Data parallelism of the training step (BASELINE configs[4]): two ranks, each with half of a seeded batch, averaging their
-    flat gradient buffers through ``allreduce_grads`` (gloo here: both ranks share the box's one GPU; RCCL on a real node), must
-    land on the parameters one rank reaches with the whole batch — the losses are batch means, so the mean of the two ranks'
-    gradients IS the whole-batch gradient."""
+    flat gradient buffers (gloo here: both ranks share the box's one GPU; RCCL on a real node), must land on the parameters one
+    rank reaches with the whole batch — the losses are batch means, so the mean of the two ranks' gradients IS the whole-batch
+    gradient.  The pair runs the BUCKETED path (five graph segments, each bucket's all-reduce issued behind its segment:
+    train.GradBucketReducer); a second pair with DHW_TRAIN_BUCKETS=0 runs the single flat all-reduce and must agree with it."""
     import socket
     import subprocess
     import sys
@@ -402,7 +403,18 @@ def test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch(tmp_pa
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path / "w2.npz")], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    a, b = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port2 = str(s.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port2, str(tmp_path / "w2flat.npz")], env=dict(env, DHW_TRAIN_BUCKETS="0")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b, bf = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz"), np.load(tmp_path / "w2flat.npz")
+    assert int(a["segments"]) == 0 and int(b["segments"]) == 5 and int(bf["segments"]) == 0     # one graph / five segments / one graph + flat all-reduce
+    # the same sums, bucket by bucket or in one piece (two runs differ at rounding level: fp32 atomics in the split-K weight gradients)
+    d2 = np.linalg.norm((b["flat"] - bf["flat"]).astype(np.float64))
+    m2 = np.linalg.norm((bf["flat"] - spec_flat()).astype(np.float64))
+    assert m2 > 1e-3 and d2 < 1e-3 * m2, ("bucketed and flat gradient all-reduce disagree", d2, m2)
     # rank 0 of the pair reports the loss of ITS half; the parameters are what must agree
     assert np.isfinite(b["losses"]).all()
     # Adam's early updates are ~ lr * g / (|g| + 1e-8): elements whose gradient is at rounding level move by a
@@ -416,6 +428,44 @@ def test_two_rank_update_equals_the_single_rank_update_on_the_whole_batch(tmp_pa
 def spec_flat():
     sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
     return np.concatenate([np.asarray(v, np.float32).ravel() for v in sd.values()])
+
+
+def test_gradient_buckets_are_final_when_their_marker_fires():
+    """The overlapped all-reduce (train.GradBucketReducer) reads bucket i of the flat gradient buffer as soon as the tape's marker
+    i fires.  That is only right if no later backward kernel adds into that range: snapshot every bucket at its marker and compare
+    with the buffer after the whole sweep, bit for bit — and the buckets must tile the buffer, every tensor in its rule's bucket."""
+    sd = spec.synthetic_state_dict(2, 128, 192, 256, seed=0)
+    B, L, Lt = 2, 64, 10
+    inp = spec.synthetic_inputs(B, L, Lt, S=14, seed=9, pad=2)
+    model = tm.TrainModel(sd, num_layers=2, device="cuda", drop_rate=0.1)
+    assert len(model.bucket_ranges) == tm.N_BUCKETS and model.bucket_ranges[0][0] == 0 and model.bucket_ranges[-1][1] == model.flat.numel()
+    for k in model.names:
+        a, b = model.bucket_ranges[tm.grad_bucket(k)]
+        assert a <= model.offset[k] and model.offset[k] + model.p[k].d.numel() <= b, k
+    g = torch.Generator().manual_seed(9)
+    x = torch.from_numpy(inp["strokes"])
+    snaps, order = {}, []
+
+    def hook(i):
+        torch.cuda.synchronize()
+        a, b = model.bucket_ranges[i]
+        snaps[i] = model.flat_grad[a:b].clone()
+        order.append(i)
+    for trial in range(2):          # (twice: the second sweep runs on a buffer that held the first one's gradients)
+        snaps.clear(), order.clear()
+        model.zero_grad()
+        score, pen = model.forward(x, torch.from_numpy(inp["text"]), torch.rand(B, 1, generator=g) * 0.8 + 0.1, torch.from_numpy(inp["style"]))
+        model.bucket_hook = hook
+        model.backward(torch.randn(score.shape, generator=g).cuda(), torch.randn(pen.shape, generator=g).cuda())
+        model.bucket_hook = None
+        torch.cuda.synchronize()
+        assert order == [0, 1, 2, 3]
+        for i, snap in snaps.items():
+            a, b = model.bucket_ranges[i]
+            assert torch.equal(snap, model.flat_grad[a:b]), f"bucket {i} received gradient after its marker (trial {trial})"
+            assert float(snap.abs().sum()) > 0
+        a, b = model.bucket_ranges[-1]
+        assert float(model.flat_grad[a:b].abs().sum()) > 0
 
 
 def test_device_drawn_encoder_dropout_trains():

@@ -91,3 +91,52 @@ def test_train_config_keys_of_the_reference_yml(tmp_path):
     bad.write_text(BEST_YML.replace("  warmup_steps: 10000\n", ""))
     with pytest.raises(KeyError, match="warmup_steps"):
         train_model.read_train_config(bad)
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    n = 10007
+    full = torch.randn(world, n, generator=g)                   # per-rank flat gradient buffers, known to all
+    ranges = [(0, 3000), (3000, 3004), (3004, 9000), (9000, 10000), (10000, n)]
+    mine = full[rank].clone()
+    red = train.GradBucketReducer(mine, ranges)
+    ok = True
+    for i in range(len(ranges) - 1):                            # in completion order, as the tape's markers fire
+        red.launch(i)
+    try:                                                        # waiting with a bucket missing is an error, not a silent partial reduce
+        red.wait()
+        ok = False
+    except RuntimeError:
+        pass
+    red.launch(len(ranges) - 1)
+    try:
+        red.launch(2)
+        ok = False
+    except RuntimeError:
+        pass
+    red.wait(average=True)
+    flat = full[rank].clone()
+    train.allreduce_grads([flat])                               # the single flat all-reduce of rounds 2-4
+    ok = ok and torch.equal(mine, flat) and torch.allclose(mine, full.mean(0), atol=1e-6)
+    red.launch(0)                                               # the reducer is reusable update after update
+    for i in range(1, len(ranges)):
+        red.launch(i)
+    red.wait()
+    ok = ok and torch.allclose(mine, full.mean(0) * world, atol=1e-5)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_equals_the_flat_one_gloo():
+    """train.GradBucketReducer (the all-reduce overlapped with the backward's tail, bucket by bucket) over a world-size-2 gloo
+    group: the buckets tile the flat buffer, each is reduced exactly once per update, and the result is the flat all-reduce's,
+    bit for bit."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bucket_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
+    with pytest.raises(ValueError):
+        train.GradBucketReducer(torch.zeros(10), [(0, 4), (5, 10)])

@@ -8,7 +8,7 @@ mkdir -p gpurun_out/$TAG
 for i in $(seq 1 $rounds); do
   for lib in "$@"; do
     L=""; [ "$lib" != "new" ] && [ -n "$lib" ] && L=$PWD/$lib
-    r=$(DHW_LIB=$L timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step --steps ${STEPS:-20} 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+    r=$(DHW_LIB=$L timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step --no-longseq --steps ${STEPS:-20} 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
     echo "round $i ${lib:-new}: $r" | tee -a gpurun_out/$TAG/ab.log
   done
 done
@@ -18,7 +18,7 @@ if [ -n "$STATS" ]; then
     L=""; [ "$lib" != "new" ] && [ -n "$lib" ] && L=$PWD/$lib
     name=$(basename "${lib:-new}" .so)
     out=$PWD/gpurun_out/$TAG/trace_$name
-    (cd /tmp && DHW_LIB=$L timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out" --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step > "$out.log" 2>&1)
+    (cd /tmp && DHW_LIB=$L timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out" --output-format csv -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step --no-longseq > "$out.log" 2>&1)
     cp $(find "$out" -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/stats_$name.csv
     rm -rf "$out"
     echo "== $name"; head -16 gpurun_out/$TAG/stats_$name.csv | cut -d, -f1-4 | sed 's/_ZN12_GLOBAL__N_1//'

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step"
+BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-fp32 --no-train-step --no-longseq"
 cd /tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- $BENCH > "$out/trace.log" 2>&1
 echo "[profile_all] kernel trace done"
@@ -25,6 +25,7 @@ timeout -k 10 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d "$out/
 echo "[profile_all] L2 pass done"
 cd - > /dev/null
 python3 tools/pmc_traffic.py "$out/fetch" "$out/write" "$out/${tag}_hbm_traffic_pmc.json" > "$out/traffic.txt"
+python3 tools/pmc_traffic_by_dispatch.py "$out/fetch" "$out/write" "$out/${tag}_hbm_traffic_by_launch.json" > "$out/${tag}_hbm_traffic_by_launch.txt"
 python3 tools/pmc_sq.py "$out/sq" "$out/${tag}_sq_counters.json" > "$out/sq.txt"
 python3 tools/pmc_insts.py "$out/insts" "$out/${tag}_inst_mix.json" > "$out/insts.txt"
 python3 tools/pmc_l2.py "$out/l2" "$out/${tag}_l2_counters.json" > "$out/l2.txt"
