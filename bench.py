@@ -363,6 +363,22 @@ def train_worker(args, dev, dist, rank, world):
                         "gemm_flops_per_update": model.last_gemm_flops}}
     if args.share_gpu:
         res["data"] = "synthetic; REHEARSAL: ranks share GPUs (not a scaling measurement)"
+    if dist is not None and world == 1 and step_fn._reducer is not None:
+        # --force-dist on one GPU: the timed run above went through the process-group path (five graph segments, Adam behind the
+        # last bucket) with the one-rank collectives SKIPPED — a SUM over one rank is the buffer itself, which is what the product
+        # does.  The same updates again with the five RCCL all-reduces forced, to rehearse the collective path: RCCL runs a one-rank
+        # all-reduce as a copy kernel (0.28 ms for the 40 MB buffer), so this figure is RCCL's own cost, not the overlap's.
+        step_fn._reducer.reduce_one_rank = True
+        for k in range(2):
+            step_fn(batch, alpha_set, args.warmup + args.steps + k + 1)
+        sync()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step_fn(batch, alpha_set, args.warmup + args.steps + k + 3)
+        sync()
+        res["rccl_one_rank_forced"] = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3, "steps": args.steps,
+                                       "note": "five bucketed RCCL all-reduces issued on a one-rank group (identity; skipped in the timed run)"}
+        step_fn._reducer.reduce_one_rank = False
     if rank == 0:
         if world == 1 and args.precision == "fp32" and not args.no_fp32:
             # the same update with mixed-precision GEMMs (bf16-rounded operands, fp32 accumulation, fp32 master weights)
@@ -540,9 +556,22 @@ def pmc_traffic(label):
         k = j["kernels"].get(name)
         if not k:
             return None
-        return {"bytes_per_launch": k["hbm_bytes_per_launch"], "fetch": k["fetch_bytes_per_launch"],
-                "write": k["write_bytes_per_launch"], "source": "profiles/" + os.path.basename(files[-1]),
-                "stale": j.get("kernel_source_hash") != kernel_source_hash()}
+        out = {"bytes_per_launch": k["hbm_bytes_per_launch"], "fetch": k["fetch_bytes_per_launch"],
+               "write": k["write_bytes_per_launch"], "source": "profiles/" + os.path.basename(files[-1]),
+               "stale": j.get("kernel_source_hash") != kernel_source_hash()}
+        # the same passes per launch POSITION of the denoiser call against activations once + the launch's weights once per XCD
+        # (8 private L2s: tools/pmc_traffic_by_dispatch.py) — what the fabric must deliver whatever the kernel does
+        by = files[-1].replace("_hbm_traffic_pmc.json", "_hbm_traffic_by_launch.json")
+        if os.path.exists(by):
+            with open(by) as f:
+                t = json.load(f)["kernels"].get(name)
+            if t:
+                sm = t["sum_over_a_call"]
+                out["per_call"] = {"pmc_bytes": sm["pmc_bytes"], "algorithmic_bytes_weights_once": sm["algorithmic_bytes_weights_once"],
+                                   "expected_bytes_weights_once_per_xcd": sm["predicted_bytes_weights_per_xcd"],
+                                   "ratio_vs_algorithmic": sm["ratio_vs_algorithmic"], "ratio_vs_expected": sm["ratio_vs_predicted"],
+                                   "source": "profiles/" + os.path.basename(by)}
+        return out
     except (OSError, ValueError, KeyError):
         return None
 

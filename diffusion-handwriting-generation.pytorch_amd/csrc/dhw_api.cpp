@@ -1874,6 +1874,9 @@ int dhw_sample(dhw_handle* h, const int64_t* text, const float* style, int B, in
       for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
       h->graphs.clear();
       if (h->d_step_sync) hipMemset(h->d_step_sync, 0, h->step_sync_words * sizeof(unsigned));
+      if (code >= 0x100u)
+        return fail(h, DHW_ERR_HIP, "persistent step kernel: XCD %u owns samples but no workgroup of the launch ran there in an EARLIER call (partitioned / "
+                    "CU-masked device?): those samples were never computed; persistent launches are now disabled for this handle", code - 0x100u);
       return fail(h, DHW_ERR_HIP, "persistent step kernel timed out waiting for phase %u in an EARLIER call (its samples were invalid); "
                   "persistent launches are now disabled for this handle", code - 1);
     }

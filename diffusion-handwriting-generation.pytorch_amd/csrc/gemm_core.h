@@ -135,8 +135,64 @@ struct WRing {
     }
     if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(DHW_EPI_PRIO);
   }
+  // ---- activation fragments requested AHEAD of their MFMAs (round 5).  In the loops above hipcc places a step's ds_read_b128
+  // directly in front of the MFMA that consumes it (`ds_read x2; s_waitcnt lgkmcnt(1); v_mfma`, in the .s of every fused kernel):
+  // each group of MT MFMAs (16 cycles each) then waits a full LDS round trip (~130-200 cycles with 8 waves reading), so ONE wave's
+  // main loop runs at 30-50 % of the matrix pipe's rate — measured with the ConvBlock row halves one phase apart (DHW_CONV_PP,
+  // profiles/r05_conv_pp_wave_stamps.log: conv1 of enc1 takes a lone wave 1.0 us for 0.32 us of MFMA issue) — and the kernels
+  // lean on the SIMD's second wave to fill the gaps.  Here chunk s + PF's MT fragments are requested BEFORE chunk s's MFMAs, into a
+  // ring of PF + 1 register sets (PF = 1: +MT x 4 VGPRs), and scheduling barriers keep hipcc from sinking the reads back.
+  // Same reads, same MFMA order per accumulator: bit-identical results.  DHW_APF = chunks ahead (0 = off).
+#ifndef DHW_APF
+#define DHW_APF 1
+#endif
+  template <int MT, int KT_, int PF>
+  DHW_DEV void run_p(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
+    if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    constexpr int ES = sizeof(T), NB = PF + 1;
+    static_assert(D % NB == 0, "the rolled part of the loop needs static fragment-ring indices");
+    constexpr int NR = KT_ > D ? KT_ - D : 0, G = NR / D;
+    Frag<T> a[NB][MT];
+    int aoff = 0, kc = 0;   // of the NEXT chunk to request
+    const int tap_step = stride - (KC - 1) * 32 * ES;
+    auto request = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) a[slot][j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+    auto step = [&](int d, int slot, bool more, bool reload, int knext) {
+      if (more) request((slot + PF) % NB);      // chunk s + PF (compile-time `more` after unrolling)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], q[d][i], a[slot][j]);
+      if (reload) load_chunk(d, knext);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+      if (c < KT_) request(c);
+    int kt = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g, kt += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) step(d, d % NB, true, true, kt + d + D);   // (G * D + PF <= KT_ - D + PF <= KT_: every rolled step has a chunk s + PF)
+    }
+#pragma unroll
+    for (int j = 0; j < KT_ - G * D; ++j) step(j % D, (G * D + j) % NB, G * D + j + PF < KT_, G * D + j + D < KT_, G * D + j + D);
+  }
   template <int MT, int KT_, int ABL = DHW_ABL>
   DHW_DEV void run_s(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
+    // DHW_APF: 1 = one chunk ahead everywhere; 2 = three chunks ahead where a chunk is fewer than 8 MFMAs (< 128 cycles of matrix work:
+    // one chunk does not cover an LDS round trip), one elsewhere
+    constexpr int PF = DHW_APF == 2 ? (NT * MT >= 8 ? 1 : 3) : DHW_APF;
+    if constexpr (PF > 0 && ABL == 0 && D % (PF + 1) == 0 && PF < D) {
+      run_p<MT, KT_, PF>(acc, abase, stride, KC);
+      return;
+    }
     if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     constexpr int ES = sizeof(T);
     constexpr int NR = KT_ > D ? KT_ - D : 0;   // steps that re-load their slot (chunk s + D exists)

@@ -20,9 +20,11 @@
 //   * tiles are handed out by ONE ticket counter per XCD for the whole call (ticket order = phase order, so a tile's
 //     dependencies always hold smaller tickets and the smallest unfinished ticket can always run: no deadlock for any
 //     number of resident workgroups per XCD); a workgroup draws its next ticket while its stores drain, so the draw's
-//     round trip (1.5-3 us under load) is off the critical path.  An XCD with samples but no workgroup, or a producer
-//     that never arrives, trips the bounded spin: the launch then finishes with the error word set (host-mapped memory,
-//     read by the next API call) instead of hanging;
+//     round trip (1.5-3 us under load) is off the critical path.  A producer that never arrives trips the consumer's
+//     bounded spin (error word = 1 + phase).  An XCD that owns samples but got no workgroup of the launch (partitioned or
+//     CU-masked device) makes nobody wait — its tiles are simply never drawn — so the LAST workgroup to leave compares every
+//     XCD's ticket counter with its tile count and sets the error word (0x100 + XCD) when one fell short.  Either way the
+//     launch finishes instead of hanging and the word (host-mapped memory) is read by the next dhw_sample call;
 //   * the counters are zeroed by the last workgroup to leave, for the next launch (stream order makes that visible).
 #pragma once
 #include "dhw_kernels.h"

@@ -186,6 +186,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     if ((unsigned)ctl[2] == gridDim.x - 1) {
       unsigned* const sync = plan->sync;
+      // Every XCD that owns samples must have run workgroups of this launch: its samples' tiles are dequeued only there.  An XCD
+      // without one (partitioned / CU-masked device, fewer than eight XCDs) leaves its ticket counter below its tile count — nobody
+      // waits on those tiles, so no bounded spin trips; the last workgroup to leave reports it (error word 0x100 + XCD, read by
+      // the next dhw_sample, which falls back to the per-kernel launches).  A served XCD ends at tiles + its resident workgroups.
+      if (threadIdx.x < STEP_XCDS) {
+        const int x = threadIdx.x, ns_x = max(0, min(c.B - x * plan->spx, plan->spx));
+        const unsigned tot = (unsigned)(ns_x * plan->cum_tps[plan->nphase]);
+        if (tot && ld_agent(sync + x * 16) < tot) __hip_atomic_store(plan->err, 0x100u + (unsigned)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();
       const int n = STEP_XCDS * 16 + STEP_MAX_PHASES * c.B + 16;
       for (int i = threadIdx.x; i < n; i += 512) sync[i] = 0u;
     }

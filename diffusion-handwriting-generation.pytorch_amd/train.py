@@ -140,7 +140,13 @@ class GradBucketReducer:
     to complete).  The 8-rank overlap itself is unmeasured here (one-GPU boxes): what is tested is that the bucketed result equals the
     single flat all-reduce (2 ranks, gloo) and that every bucket's gradients are final when its marker fires (GPU test)."""
 
-    def __init__(self, flat_grad: torch.Tensor, ranges):
+    def __init__(self, flat_grad: torch.Tensor, ranges, reduce_one_rank: bool | None = None):
+        """``reduce_one_rank``: issue the collectives even in a one-rank group, where every all-reduce is the identity (default: env
+        DHW_TRAIN_REDUCE_ONE_RANK=1, else skip them).  RCCL executes a one-rank all-reduce as a real copy kernel — 0.28 ms for the
+        40 MB buffer on MI355X (profiles/r05_train_dist_overhead.log) — which a product run has no reason to pay; the RCCL rehearsal
+        on a one-GPU box (tests/test_gpu_train.py, bench.py --force-dist) forces it."""
+        import os
+        self.reduce_one_rank = (os.environ.get("DHW_TRAIN_REDUCE_ONE_RANK", "0") == "1") if reduce_one_rank is None else bool(reduce_one_rank)
         self.flat_grad, self.ranges = flat_grad, [tuple(r) for r in ranges]
         if any(a >= b for a, b in self.ranges) or any(self.ranges[i][1] != self.ranges[i + 1][0] for i in range(len(self.ranges) - 1)) \
                 or self.ranges[0][0] != 0 or self.ranges[-1][1] != flat_grad.numel():
@@ -153,6 +159,8 @@ class GradBucketReducer:
             raise RuntimeError(f"gradient bucket {i} reduced twice in one update")
         a, b = self.ranges[i]
         self.launched.append(i)
+        if dist.get_world_size() == 1 and not self.reduce_one_rank:
+            return                      # the SUM over one rank is the buffer itself
         self.works.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self, average: bool = False, world_size: int | None = None):

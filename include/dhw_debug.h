@@ -32,8 +32,9 @@ int dhw_set_streams(dhw_handle*, int n);
 
 /* Use (1) or bypass (0) hipGraph replay of the sampling loop. Default 1. */
 int dhw_set_graph(dhw_handle*, int on);
-/* Number of dhw_sample shapes that run every denoiser call as ONE persistent launch (csrc/persist.h; env DHW_PERSIST=0 at
-   dhw_create turns that form off).  0 = every call so far was launched kernel by kernel. */
+/* Number of dhw_sample shapes that run every denoiser call as ONE persistent launch (csrc/persist.h; OFF by default — it measured
+   slower than the eleven launches, DESIGN 13.3 — env DHW_PERSIST=1 at dhw_create turns that form on).  0 = every call so far was
+   launched kernel by kernel. */
 int dhw_debug_persist_plans(dhw_handle*);
 /* Diagnostics (DHW_PERSIST_TRACE=1 at dhw_create): 100 MHz time stamps of the last persistent step of the last dhw_sample call,
    [workgroup][16 phases][4] = {ticket drawn, inputs ready, body done, (phase 0: kernel entry; phase 1: exit | xcc << 56)}.

@@ -21,9 +21,11 @@ acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(lambda: defaultdi
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path, newline="")):
         k = row["Kernel_Name"]
+        if "convblock_kernel" not in k: continue
+        # template arguments <T, BM, CO, NW, OCC, UPC, CH, CIN, TIGHT, PP> from the demangled or the mangled (…ILi128ELi128E…) name
         m = re.search(r"convblock_kernel<([^>]*)>", k)
-        if not m: continue
-        acc[m.group(1)][row["Counter_Name"]] += float(row["Counter_Value"]); n[m.group(1)][row["Counter_Name"]] += 1
+        key = m.group(1) if m else ",".join(re.findall(r"Li(\d+)E", k))
+        acc[key][row["Counter_Name"]] += float(row["Counter_Value"]); n[key][row["Counter_Name"]] += 1
 for k in sorted(acc):
     a = {c: acc[k][c] / max(n[k][c], 1) for c in acc[k]}
     busy, co = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), a.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0)

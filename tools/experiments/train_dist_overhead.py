@@ -15,6 +15,7 @@ import torch.distributed as dist
 from dhg_amd import spec, train, train_model as tm
 
 mode = sys.argv[1]
+torch.set_num_threads(8)   # (the host side assembles the batch with small torch CPU ops: uncapped threads on a shared box cost ~15 ms per update)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 if mode in ("seg_bucketed", "flat", "seg_noreduce"):
