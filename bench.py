@@ -297,7 +297,8 @@ def worker(args):
 
 def train_worker(args, dev, dist, rank, world):
     """--train: K updates of the native training step (dhg_amd.train_model.GraphedTrainStep) on one synthetic batch per
-    rank; N > 1 averages the flat gradient buffer with one RCCL all-reduce per update (data parallel, weak scaling)."""
+    rank; N > 1 sums the flat gradient buffer across ranks in five bucketed RCCL all-reduces overlapped with the backward's tail
+    (train.GradBucketReducer; data parallel, weak scaling)."""
     import numpy as np
     import torch
     from dhg_amd import spec, train, train_model as tm
@@ -355,7 +356,7 @@ def train_worker(args, dev, dist, rank, world):
            "config": {"workload": f"configs[4]: training step, batch={B}/GPU, L={L}, Lt={Lt}, d_model=128/192/256, num_layers={args.num_layers}, "
                                   "dropout 0.0 + style Dropout(0.3), Adam + Noam + clip 100, random-init weights",
                       "global_batch": world * B, "seq_len": L,
-                      "parallelism": f"data-parallel x{world}" + (" (one all-reduce of the flat 40 MB gradient buffer per update)" if world > 1 else "")},
+                      "parallelism": f"data-parallel x{world}" + (" (gradient all-reduce in 5 buckets, each issued behind its graph segment of the backward; Adam applies 1 / world)" if world > 1 else "")},
            "per_rank_ms": [t / args.steps * 1e3 for t in per_rank], "loss_first_last": [lv[0], lv[-1]],
            "launches_per_update": model.last_launches, "launch": "eager" if args.no_graph else "hipGraph",
            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_F32_TFLOPS,

@@ -144,7 +144,7 @@ struct WRing {
   // ring of PF + 1 register sets (PF = 1: +MT x 4 VGPRs), and scheduling barriers keep hipcc from sinking the reads back.
   // Same reads, same MFMA order per accumulator: bit-identical results.  DHW_APF = chunks ahead (0 = off).
 #ifndef DHW_APF
-#define DHW_APF 1
+#define DHW_APF 3
 #endif
   template <int MT, int KT_, int PF>
   DHW_DEV void run_p(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
@@ -188,7 +188,8 @@ struct WRing {
   DHW_DEV void run_s(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
     // DHW_APF: 1 = one chunk ahead everywhere; 2 = three chunks ahead where a chunk is fewer than 8 MFMAs (< 128 cycles of matrix work:
     // one chunk does not cover an LDS round trip), one elsewhere
-    constexpr int PF = DHW_APF == 2 ? (NT * MT >= 8 ? 1 : 3) : DHW_APF;
+    // 3 = three chunks ahead only for single-row-tile loops (MT = 1: the 16-row EncoderLayer tiles, 4 VGPRs per chunk), one elsewhere
+    constexpr int PF = DHW_APF == 2 ? (NT * MT >= 8 ? 1 : 3) : DHW_APF == 3 ? (MT == 1 ? 3 : 1) : DHW_APF;
     if constexpr (PF > 0 && ABL == 0 && D % (PF + 1) == 0 && PF < D) {
       run_p<MT, KT_, PF>(acc, abase, stride, KC);
       return;
