@@ -233,6 +233,45 @@ DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], 
   const int g = lane >> 4;
   const float c = rsqrtf((float)D) * 1.4426950408889634f;
   f32x4 s[NU][NTILE];
+  // DHW_ATT_KPF (round 5): a unit's NTILE x KCH key fragments are all requested BEFORE its QK^T MFMAs (hipcc otherwise places each
+  // ds_read_b128 directly in front of the MFMA that consumes it: one LDS round trip per MFMA, as in the GEMM main loops — gemm_core.h, run_p);
+  // 2 = both units' fragments before the first MFMA.  Same reads, same MFMAs: bit-identical.
+#ifndef DHW_ATT_KPF
+#define DHW_ATT_KPF 1
+#endif
+  if constexpr (DHW_ATT_KPF != 0 && DHW_ATT_ABL == 0) {
+    Frag<T> kf[NU][NTILE][KCH];
+    auto request = [&](int u) {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int ch = 0; ch < KCH; ++ch) kf[u][t][ch] = frag_load(reinterpret_cast<const T*>(kt[u] + t * 16 * SK) + 32 * ch + 8 * g);
+    };
+    auto multiply = [&](int u) {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        s[u][t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < KCH; ++ch) mma32(s[u][t], kf[u][t][ch], qf[u][ch]);
+      }
+    };
+    if constexpr (DHW_ATT_KPF == 2) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) request(u);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) multiply(u);
+    } else {
+      request(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) request(u + 1);     // the next unit's fragments fly under this unit's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -246,6 +285,7 @@ DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], 
         else mma32(s[u][t], kf, qf[u][ch]);
       }
     }
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u)
 #pragma unroll

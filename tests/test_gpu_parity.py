@@ -371,7 +371,8 @@ def test_sampler_switches_do_not_change_the_samples(prec):
                       ("no_fused_up", {"DHW_FUSE_UP": "0"}), ("no_chain", {"DHW_CHAIN": "0"}), ("conv_chain", {"DHW_CHAIN_CONV": "3"}),
                       ("no_conv_chain", {"DHW_CHAIN_CONV": "0"}),
                       ("enc_bm64", {"DHW_ENC_BM": "64"}), ("enc_bm32", {"DHW_ENC_BM": "32"}), ("conv_bm64", {"DHW_CONV_BM": "64"}),
-                      ("f32_enc_per_gemm", {"DHW_FUSE_F32": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"})):
+                      ("f32_enc_per_gemm", {"DHW_FUSE_F32": "0"}), ("unfused", {"DHW_FUSE": "0", "DHW_PLANE": "0"}),
+                      ("unfused_text_plane", {"DHW_FUSE_TEXT": "0"}), ("unfused_plane", {"DHW_FUSE": "0"})):
         m = _fresh_model(prec, env, B=B, L=L, Lt=Lt)
         outs[name] = dhg_amd.sample(m, tx, sv, L=L, T=T, noise=nz).cpu()
         # DHW_PERSIST=1 (bf16): every denoiser call is ONE persistent launch (csrc/persist.h); every other configuration launches kernel by kernel
@@ -393,6 +394,9 @@ def test_sampler_switches_do_not_change_the_samples(prec):
     for k in ("enc_bm64", "enc_bm32", "conv_bm64"):
         assert (outs["default"] - outs[k]).abs().max().item() < tol, k
     assert (outs["default"] - outs["unfused"]).abs().max().item() < tol
+    # the all-steps text plane through the generic GEMM / attention launches (its own ".T" workspace buffers), with the fused stroke kernels and without
+    assert (outs["default"] - outs["unfused_text_plane"]).abs().max().item() < tol
+    assert (outs["default"] - outs["unfused_plane"]).abs().max().item() < tol
 
 
 def test_convblock_row_halves_one_phase_apart_give_the_same_bits():
