@@ -74,6 +74,7 @@ hipError_t convblock_init() {
   A(bf16_t, 32, 256, 8, 1, 0, 0, 192, 2); A(bf16_t, 32, 256, 8, 1, 384, 0, 384, 2);       // 32-row tiles of the widest blocks, conv1 over 48 rows (TIGHT = 2)
   // encoder blocks that continue into the next EncoderLayer's first half
   A(bf16_t, 64, 192, 8, 1, 0, 1, 128); A(bf16_t, 48, 256, 8, 1, 0, 1, 192); A(bf16_t, 64, 256, 8, 1, 0, 1, 192);
+  A(bf16_t, 32, 256, 8, 1, 0, 1, 192, 2);   // ... on the asymmetric 32-row tiles (the layer's own 32-row tiling: enc4 -> enc5.a)
   A(float, 32, 128, 4); A(float, 32, 192, 4); A(float, 32, 256, 4);
 #undef A
   return hipSuccess;
@@ -167,8 +168,14 @@ bool convblock_chain_supported(int prec, const ConvBlockParams& p, const EncChai
   return (p.Cout == 192 || p.Cout == 256) && p.Cin == enc_cin(p.Cout) && enclayer_supported(prec, chain.a.d, chain.a.heads);
 }
 
+// Whether continuing this block into the next EncoderLayer's first half is a measured WIN for its launch geometry (the default of
+// DHW_CHAIN_CONV for enc4 -> enc5.a): only on the asymmetric 32-row tiles, which are the layer's own tiling (r5: 18.02 -> 17.89 ms
+// same-box, profiles/r05_enc4_chain_ab.log; on the 46-row tiles the chain measured slower in rounds 1 and 3).
+bool convblock_chain_auto(const ConvBlockParams& p) { return p.Cout == 256 && use_asym32(p); }
+
 hipError_t launch_convblock_chain(int prec, const ConvBlockParams& p, const EncChain& chain, hipStream_t st) {
   if (!convblock_chain_supported(prec, p, chain) || p.Cin % 32 || (!p.out)) return hipErrorInvalidValue;
   if (p.Cout == 192) return launch_t<bf16_t, 64, 192, 8, 1, 0, 1, 128>(p, st, &chain);
+  if (use_asym32(p)) return launch_t<bf16_t, 32, 256, 8, 1, 0, 1, 192, 2>(p, st, &chain);
   return use_bm48(p) ? launch_t<bf16_t, 48, 256, 8, 1, 0, 1, 192>(p, st, &chain) : launch_t<bf16_t, 64, 256, 8, 1, 0, 1, 192>(p, st, &chain);
 }

@@ -108,7 +108,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT1 = BM1 / WM1 / 16, NT1 = T1 / WN1;
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
-  static_assert(!ASYM || (CH == 0 && WM1 == 1), "the asymmetric tiling: plain blocks with one row group in conv1");
+  static_assert(!ASYM || WM1 == 1, "the asymmetric tiling: blocks with one row group in conv1");
   constexpr bool PPX = PP != 0;
   static_assert(!PPX || (TALL && WM1 == 2 && WN1 == 4 && CH == 0 && !ASYM && OCC == 1), "ping-pong: the 2 x 4 wave layouts of the tall tiles");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
@@ -445,7 +445,7 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       m.VT = m.KT + 32 * tile_stride<T>(CO);
       m.VS = smem;
       m.PL = reinterpret_cast<float*>(m.KT + enc_a_text_kv_bytes<T, CO, BM>());
-      enc_a_body<T, CO, BM, 4>(nx.a, m, b, m0, rows_valid);   // (tile starts are multiples of BM - 2: even, not 8-aligned)
+      enc_a_body<T, CO, BM, (ASYM ? 16 : 4)>(nx.a, m, b, m0, rows_valid);   // (tile starts are multiples of BM - 2: even, not 8-aligned; of BM for the asymmetric tiling)
     }
   }
   STAMP(9);

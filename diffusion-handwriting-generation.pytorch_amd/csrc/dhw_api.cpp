@@ -804,9 +804,10 @@ struct UpIn { const void* hskip; const void* w; const float* b; int cin; const v
 // cnn.py:64-87 as one fused launch (or three fused GEMM launches)
 // chain: the EncoderLayer half the block's workgroups continue with (EncChain mode 1), or null; *chained reports
 // whether the launch took it
+// chain_auto: take the chain only where convblock_chain_auto says it pays for this launch geometry
 void conv_block(Ctx& c, int id, const ConvBlockW& w, const void* x, int L, void* out, bool out_f32,
                 void* pool, const float* strokes = nullptr, const UpIn* up = nullptr, const EncChain* chain = nullptr,
-                bool* chained = nullptr) {
+                bool* chained = nullptr, bool chain_auto = false) {
   dhw_handle* h = c.h;
   const char* n = kConvName[id];
   if (h->fuse) {
@@ -828,7 +829,7 @@ void conv_block(Ctx& c, int id, const ConvBlockW& w, const void* x, int L, void*
     }
     if (c.rec) {
       // the phase kinds the persistent kernel is built with (persist.h): the reference's widths, the canonical row tiles
-      const bool ch = chain && chain->mode == 1 && convblock_chain_supported(h->prec, q, *chain);
+      const bool ch = chain && chain->mode == 1 && convblock_chain_supported(h->prec, q, *chain) && (!chain_auto || convblock_chain_auto(q));
       if (chained) *chained = ch;
       int kind = -1;
       if (id == CB_ENC1 && strokes && !up) kind = PK_CONV_ENC1;
@@ -844,7 +845,7 @@ void conv_block(Ctx& c, int id, const ConvBlockW& w, const void* x, int L, void*
     if (!c.err) {
       const double rows = (double)c.B * L;
       const double upf = up ? 3.0 * up->cin * w.cin : 0.0;   // skip_conv MACs per row
-      const bool ch = chain && chain->mode && convblock_chain_supported(h->prec, q, *chain);
+      const bool ch = chain && chain->mode && convblock_chain_supported(h->prec, q, *chain) && (!chain_auto || convblock_chain_auto(q));
       if (chained) *chained = ch;
       const double dd = w.cout;
       const double chf = ch ? 2.0 * rows * dd * dd * 5 + 4.0 * rows * c.Lt * dd : 0.0, chb = ch ? rows * dd * 4 * h->es + 5.0 * dd * dd * h->es : 0.0;
@@ -1244,7 +1245,10 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   // enc2 / enc4 can continue into enc3.a / enc5.a the same way (bit 0 / bit 1), but the ConvBlock's row tiling (62 / 46 rows)
   // is a worse fit for the layer than its own: r1 measured 23.22 ms (off) / 23.21 (enc3) / 23.40 (enc5, both); r3, after the kernels
   // changed: 19.54 (off) / 19.40 (enc3: bit 0) / 19.62 (enc5: bit 1) / 19.45 (both), three alternating runs each -> enc3 only
-  static const int conv_chain = getenv("DHW_CHAIN_CONV") ? atoi(getenv("DHW_CHAIN_CONV")) : 1;
+  // r5: with enc4 on the asymmetric 32-row tiles (B = 64 at L / 4 = 122: the layer's own tiling) the enc5 chain wins, 18.02 -> 17.89 ms: the default
+  // (no DHW_CHAIN_CONV) takes bit 1 exactly there (convblock_chain_auto); an explicit DHW_CHAIN_CONV forces / forbids it for any tiling
+  static const bool conv_chain_env = getenv("DHW_CHAIN_CONV") != nullptr;
+  static const int conv_chain = conv_chain_env ? atoi(getenv("DHW_CHAIN_CONV")) : 3;
   {
     EncChain ch{};
     if (chain_ok && (conv_chain & 1)) { ch.mode = 1; ch.a = enc_params(c, 0, h->el[0], nullptr, L / 2, h->lpadX[0], text, nullptr); }
@@ -1253,8 +1257,9 @@ void stroke_path(Ctx& c, const float* strokes, const int64_t* text) {
   enc_layer(c, 0, h->el[0], CBB(c, CB_ENC2, out), L / 2, h->lpadX[0], text, WS(c, enc3_pool), a3);
   {
     EncChain ch{};
-    if (chain_ok && (conv_chain & 2)) { ch.mode = 1; ch.a = enc_params(c, 1, h->el[1], nullptr, L / 4, h->lpadX[1], text, nullptr); }
-    conv_block(c, CB_ENC4, h->enc4, WS(c, enc3_pool), L / 4, CBB(c, CB_ENC4, out), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a5);
+    // (record mode: the persistent step kernel has enc4 and enc5.a as two phases)
+    if (chain_ok && (conv_chain & 2) && !c.rec) { ch.mode = 1; ch.a = enc_params(c, 1, h->el[1], nullptr, L / 4, h->lpadX[1], text, nullptr); }
+    conv_block(c, CB_ENC4, h->enc4, WS(c, enc3_pool), L / 4, CBB(c, CB_ENC4, out), false, nullptr, nullptr, nullptr, ch.mode ? &ch : nullptr, &a5, !conv_chain_env);
   }
   EncChain ch5{};
   if (chain_ok && nl > 0 && enclayer_supported(h->prec, dt, h->el[2].heads) && enclayer_chain_supported(h->prec, d.c3, c.B, L / 4, 2, dt)) {

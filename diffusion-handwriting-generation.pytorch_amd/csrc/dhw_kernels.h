@@ -128,6 +128,7 @@ struct EncChain {
 // A ConvBlock whose output feeds an EncoderLayer continues into that layer's enc_a on its own output tile (mode 1).
 bool convblock_chain_supported(int prec, const ConvBlockParams& p, const EncChain& chain);
 hipError_t launch_convblock_chain(int prec, const ConvBlockParams& p, const EncChain& chain, hipStream_t st);
+bool convblock_chain_auto(const ConvBlockParams& p);   // the chain is a measured win for this launch geometry (enc4 on the asymmetric 32-row tiles)
 bool enclayer_supported(int prec, int d, int heads);
 // whether enc_bc of a (d, B, Lk) layer can continue with `mode`; mode 2 needs EncLayerParams.bm_min = 32 on that layer
 bool enclayer_chain_supported(int prec, int d, int B, int Lk, int mode, int d_next);
