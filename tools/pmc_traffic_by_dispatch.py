@@ -40,7 +40,7 @@ def per_dispatch(d, counter):
     return [(did, name[did], agg[did]) for did in sorted(agg)]
 
 
-def predictions(B, L, Lt):
+def predictions(B, L, Lt, chain5=True):
     """position -> (label, activation bytes, weight bytes) for the reference dims c = (128, 192, 256), num_layers = 2"""
     c1, c2, c3, dt = 128, 192, 256, 384
     rows = lambda lv: B * L // lv   # noqa: E731
@@ -61,10 +61,11 @@ def predictions(B, L, Lt):
     def enc_bc(r, d, pool=False):   # reads x2 + [q2|k2|v2], writes out (+ pool); weights: dense2, ffn = 5 d^2
         return r * d * ES * (5 + (0.5 if pool else 0.0)), 5 * d * d * ES
 
-    a3c, a5, aac = enc_a(rows(2), c2, L // 2, True), enc_a(rows(4), c3, L // 4, False), enc_a(rows(8), dt, L // 8, True)
+    # (enc4 continues into enc5.a since round 5 on the asymmetric 32-row tiles: DHW_CHAIN_CONV default; pass chain5=False for older builds)
+    a3c, a5, aac = enc_a(rows(2), c2, L // 2, True), enc_a(rows(4), c3, L // 4, chain5), enc_a(rows(8), dt, L // 8, True)
     conv = [("enc1", rows(1) * 2 * 4 + rows(1) * c1 * ES * 1.5, cb_w(c1, c1)),     # (reads the 2-float strokes, writes out + pool)
             ("enc2 -> enc3.a", cb_a(rows(2), c1, c2) + a3c[0], cb_w(c1, c2) + a3c[1]),
-            ("enc4", cb_a(rows(4), c2, c3), cb_w(c2, c3)),
+            ("enc4 -> enc5.a", cb_a(rows(4), c2, c3) + a5[0], cb_w(c2, c3) + a5[1]) if chain5 else ("enc4", cb_a(rows(4), c2, c3), cb_w(c2, c3)),
             ("dec3", cb_a(rows(4), dt, c3, up=c3), cb_w(dt, c3, up=c3)),
             ("dec2", cb_a(rows(2), c3, c2, up=c2), cb_w(c3, c2, up=c2)),
             ("dec1 (+ heads, scheduler step)", cb_a(rows(1), c2, c1, up=c1, heads=True) + rows(1) * 2 * 4 * 2, cb_w(c2, c1, up=c1))]
@@ -73,13 +74,16 @@ def predictions(B, L, Lt):
              ("enc5.bc -> pool -> att_dense -> att0.a", bc5[0] + rows(8) * dt * ES + aac[0], bc5[1] + c3 * dt * ES + aac[1]),
              ("att0.bc -> att1.a", bca[0] + aac[0], bca[1] + aac[1]),
              ("att1.bc", bca[0], bca[1])]
-    return {"convblock_kernel": conv, "enc_bc_kernel": encbc, "enc_a_kernel": [("enc5.a", a5[0], a5[1])]}
+    out = {"convblock_kernel": conv, "enc_bc_kernel": encbc}
+    if not chain5:
+        out["enc_a_kernel"] = [("enc5.a", a5[0], a5[1])]
+    return out
 
 
 def main():
     fdir, wdir, out = sys.argv[1:4]
     B, L, Lt = (int(x) for x in sys.argv[4:7]) if len(sys.argv) >= 7 else (64, 488, 30)
-    pred = predictions(B, L, Lt)
+    pred = predictions(B, L, Lt, chain5=os.environ.get("DHW_CHAIN_CONV", "3") not in ("0", "1"))
     res = {}
     for counter, d, scale in (("FETCH_SIZE", fdir, 2048.0), ("WRITE_SIZE", wdir, 1024.0)):
         count = defaultdict(int)
