@@ -457,7 +457,10 @@ hipError_t launch_text_style(int prec, const TextStyleParams& p, hipStream_t st)
 hipError_t launch_text_layer(int prec, const TextLayerParams& p, hipStream_t st) {
   if (prec != PREC_BF16 || p.Lt < 1 || p.Lt > 32 || p.n < 1 || p.film_div < 1 || p.lpadT < 32 || p.lpadT % 8) return hipErrorInvalidValue;
   // two pairs per workgroup where consecutive pairs share their FiLM row (the all-steps text plane with an even batch) (p.pairs: dhw_create's DHW_TEXT_PAIRS = 1 / 2 forces either form; A/B, equivalence test)
-  const bool two = p.film_div % 2 == 0 && p.pairs == 2;   // (measured equal: 18.72 vs 18.73 ms per 60-step batch, profiles/r04_text_pairs_ab.log — off unless forced)
+  // r4 measured the two forms equal (18.72 vs 18.73 ms per 60-step batch, profiles/r04_text_pairs_ab.log); with the activation fragments requested
+  // ahead of their MFMAs (r5, gemm_core.h run_p) the 64-row form is ahead — 18.52 -> 18.44 / 18.48 ms same-box, profiles/r05_switches_ab.log — and is
+  // the default where the plane is large enough to fill the CUs with one workgroup each (>= 1024 pairs); DHW_TEXT_PAIRS=1 forces one pair per workgroup
+  const bool two = p.film_div % 2 == 0 && (p.pairs == 2 || (p.pairs == 0 && p.n >= 1024));
 #define DHW_TL_LAUNCH(D_) \
   if (two) hipLaunchKernelGGL((text_layer_kernel<bf16_t, D_, 2>), dim3((p.n + 1) / 2), dim3(512), (text_layer_lds<D_, 2>()), st, p); \
   else hipLaunchKernelGGL((text_layer_kernel<bf16_t, D_, 1>), dim3(p.n), dim3(512), (text_layer_lds<D_, 1>()), st, p)
