@@ -187,6 +187,11 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   constexpr int RINGA = sizeof(T) == 4 ? 12 : (DM == 384 && BM == 16 ? DHW_RINGA384 : 24);
   typedef WRing<T, NT, (XS ? XDE * NT : RINGA), (XS ? XDE : (RINGA + NT - 1) / NT)> RingT;
   RingT ring;
+#ifndef DHW_ENC_SPREAD
+#define DHW_ENC_SPREAD 3   // bit 0: enc_bc's stages (enc_bc_core.h), bit 1: enc_a's
+#endif
+  constexpr bool SPREADA = sizeof(T) == 2 && (DHW_ENC_SPREAD & 2) != 0 && !XS;
+  constexpr int FCHA = RingT::template fill_chunks<KC>(), FQA = (FCHA + 3) / 4;
   EpiParams<NT> ep;
   ENC_STAMP(0);
   // x tile, first block of text keys and of text values (usually all of them): every load is requested before the first
@@ -329,14 +334,19 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       if constexpr (XS) ring.template run_x<MT, KC, 0, KC>(acc, qop, S, KC, reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // + the q2 chunk's weights
       else ring.template run_s<MT, KC>(acc, qop, S, KC);
       ENC_STAMP(10);
-      if constexpr (!XS) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
+      // the q2 chunk's first fragments: spread through the LayerNorm epilogue (SPREADA, as enc_bc_core.h DHW_ENC_SPREAD) or one burst in front of it
+      if constexpr (SPREADA) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane); ring.template fill_range<KC, 0, FQA>(); }
+      else if constexpr (!XS) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + wlane);   // q2 chunk: flies during the LayerNorm epilogue
       if constexpr (PLDS) ep.lds(PL + DM, PL + 2 * DM, PL + 3 * DM, n0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
+      if constexpr (SPREADA) ring.template fill_range<KC, FQA, 2 * FQA>();
     }
-    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
+    if constexpr (SPREADA) ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act, [&]() { if (act) ring.template fill_range<KC, 2 * FQA, 3 * FQA>(); });
+    else ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);
+    if constexpr (SPREADA) { if (act) ring.template fill_range<KC, 3 * FQA, FCHA>(); }
     ENC_STAMP(11);
     if (act) {
       // x2 replaces x in LDS (x is no longer an operand: q1 finished two barriers ago).  A 16-byte paired store covers the
@@ -388,7 +398,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       }
       ENC_STAMP(12 + chunk);
       if constexpr (PLDS) ep.lds_bias(PL + (4 + chunk) * DM, n0 + opaque);
-      if constexpr (!XS) { if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); }
+      if constexpr (SPREADA && MT == 1) {
+        // (the single-row-tile form stores straight from the accumulators below: its few VALU + store instructions go between the request's halves)
+        if (chunk < 2) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); ring.template fill_range<KC, 0, 2 * FQA>(); }
+      } else if constexpr (!XS) { if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); }
     }
     if (rows_out && MT == 1) {
       // one row tile per wave (3 store instructions per chunk): straight from the accumulators, no LDS round trip
@@ -398,6 +411,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
         for (int i = 0; i < NT; ++i)
           store4(reinterpret_cast<T*>(p.qk2) + (unsigned)((b * p.Lk + m0 + r) * QKS + chunk * DM + n0 + 16 * i + opaque), acc[i][0] + ep.bias[i] + pb[i][0]);
       }
+      if constexpr (SPREADA && MT == 1) { if (act && chunk < 2) ring.template fill_range<KC, 2 * FQA, FCHA>(); }
       ENC_STAMP(5 + chunk);
       return;
     }

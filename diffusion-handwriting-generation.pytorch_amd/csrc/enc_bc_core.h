@@ -117,6 +117,12 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   const char* op3 = R3 + (row0 + l15) * S + g * 8 * ES;
 
   WRing<T, NT, RING, RDMAX> ring;
+#ifndef DHW_ENC_SPREAD
+#define DHW_ENC_SPREAD 3   // bit 0: this kernel's stages, bit 1: enc_a's (enc_a_core.h)
+#endif
+  constexpr bool SPREAD = sizeof(T) == 2 && (DHW_ENC_SPREAD & 1) != 0;
+  constexpr bool SPREAD_ATT = sizeof(T) == 2 && (DHW_ENC_SPREAD & 4) != 0 && !DHW_ENC_EARLYFILL && !DHW_ENC_XSTREAM;   // bit 2: the dense stage's request around the last key block
+  constexpr int FCH = WRing<T, NT, RING, RDMAX>::template fill_chunks<KC>(), FQ = (FCH + 3) / 4;   // ring slots a stage's first request fills, and a quarter of them
   // slot rotation of the stages (gemm_core.h): dense 0, FFN first halves ROT1, second halves ROT2 — and back to ROT1, so the loop over the
   // two halves of the hidden layer stays rolled
   typedef WRing<T, NT, RING, RDMAX> RingT;
@@ -200,6 +206,12 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       char* VT = KT + KBS * SK;
       char* KN = R2 + (DB && !(ib & 1) ? BUFB : 0);   // where the next block goes
       if (DB && more) request(kb + KBS);
+      if constexpr (SPREAD_ATT) {
+        // the post-attention stage's first weight fragments: half of them in front of the LAST key block's math (no K / V request follows them,
+        // so nothing the attention waits for queues behind them — the r4 EARLYFILL form put all of them in front of the FIRST block), the
+        // other half behind the a2 stores below
+        if (!more && act) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane); ring.template fill_range<KC, 0, 2 * FQ>(); }
+      }
       if (ib < 3) STAMP(26 + 2 * ib);
       attn_units<T, KBS, false, UMAX>(lane, qf, KT, SK, VT, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
       if (ib < 3) STAMP(27 + 2 * ib);
@@ -250,7 +262,10 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     cp.template store<DM>(PL, tid);
   }
   if (act) {
-    if (!EARLY || (p.dbg & 1)) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
+    if constexpr (SPREAD_ATT) {
+      if (p.dbg & 1) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);
+      else ring.template fill_range<KC, 2 * FQ, FCH>();
+    } else if (!EARLY || (p.dbg & 1)) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane);   // in flight across the barrier
     if constexpr (!PLDS) ep.load(p.b_d2, gam + p.f2, bet + p.f2, n0);
   }
   WST(2);
@@ -279,7 +294,12 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       } else {
         ring.template run_s<MT, KC>(acc, op1, S, KC);
         WST(4);
-        ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
+        // FFN half 0's first fragments.  DHW_ENC_SPREAD (round 5): requested a few chunks at a time BETWEEN the pieces of the epilogue below
+        // instead of as one burst in front of it — a wave that requests its whole ring at once sits in instruction issue until the CU's L1
+        // path has accepted all of it (per-wave timelines at HEAD, profiles/r05_encbc_wave_timeline_d384.log: "f1.fill" 1.2-2.9 kcycles
+        // per stage, during which no wave of the workgroup executes the LayerNorm / FiLM / SiLU work that follows)
+        if constexpr (SPREAD) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane); ring.template fill_range<KC, 0, FQ>(); }
+        else ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_f1) + wlane);   // FFN half 0: flies during the LayerNorm epilogue
       }
       WST(5);
       if constexpr (PLDS) ep.lds(PL, PL + DM, PL + 2 * DM, n0);
@@ -287,10 +307,12 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + res[i][j];
+      if constexpr (SPREAD && !XS) ring.template fill_range<KC, FQ, 2 * FQ>();
     }
     STAMP(18);
     WST(6);
-    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
+    if constexpr (SPREAD && !XS) ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act, [&]() { if (act) ring.template fill_range<KC, 2 * FQ, 3 * FQ>(); });
+    else ln_rows<T, MT, NT, WN, BM>(acc, red, wn, row0, lane, DM, act);   // its barriers also fence the a2 reads above
     WST(7);
     if (act) {
       // x3 -> R2, SiLU(x3) -> R1: whole-tile-group SiLU and 16-byte paired stores (epilogue.h)
@@ -299,6 +321,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i];
       enc_store_tiles<T, NT, MT>(lane, R2, S, row0, n0, acc);
+      if constexpr (SPREAD && !XS) ring.template fill_range<KC, 3 * FQ, FCH>();
       silu_tiles2<T, NT, MT>(acc);
       enc_store_tiles<T, NT, MT>(lane, R1, S, row0, n0, acc);
     }
@@ -323,14 +346,18 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       else ring.template run_s<MT, KC>(acc, op1, S, KC);
       WST(10 + 6 * hh);
       if constexpr (PLDS) ep.lds_bias(PL + (3 + hh) * DM, n0);
-      if constexpr (!XS) ring.template fill_s<KC>(w2, 2 * KC);   // flies during the SiLU epilogue and the barrier
+      if constexpr (SPREAD && !XS) { ring.template fill_begin<KC>(w2, 2 * KC); ring.template fill_range<KC, 0, FQ>(); }
+      else if constexpr (!XS) ring.template fill_s<KC>(w2, 2 * KC);   // flies during the SiLU epilogue and the barrier
       WST(11 + 6 * hh);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
+      if constexpr (SPREAD && !XS) ring.template fill_range<KC, FQ, 2 * FQ>();
       silu_tiles2<T, NT, MT>(acc);
+      if constexpr (SPREAD && !XS) ring.template fill_range<KC, 2 * FQ, 3 * FQ>();
       enc_store_tiles<T, NT, MT>(lane, R3, S, row0, n0, acc);
+      if constexpr (SPREAD && !XS) ring.template fill_range<KC, 3 * FQ, FCH>();
     }
     WST(12 + 6 * hh);
     lds_barrier();

@@ -119,6 +119,12 @@ struct WRing {
   DHW_DEV void fill_chunk(int d) {   // d: compile-time constant after unrolling
     if (d < fill_chunks<KT_>()) load_chunk(d, d);
   }
+  // ring slots [A, B) of the stage announced by fill_begin (compile-time bounds: static register indices)
+  template <int KT_, int A, int B>
+  DHW_DEV void fill_range() {
+#pragma unroll
+    for (int d = A; d < B; ++d) fill_chunk<KT_>(d);
+  }
   template <int KT_>
   DHW_DEV void fill_s(const T* __restrict__ wbase, int kts = 0) {
     base = wbase;
@@ -248,18 +254,31 @@ struct WRing {
     constexpr int ES = sizeof(T), DE = eff_depth<KT_>();
     static_assert(KTN_ == 0 || eff_depth<KTN_>() == DE, "the next stage must use the same ring depth");
     const int nKTS = nkts ? nkts : KTN_;
-    int aoff = 0, kc = 0;
+    int aoff = 0, kc = 0;   // of the NEXT chunk of activation fragments to request
     const int tap_step = stride - (KC - 1) * 32 * ES;
+    // (round 5: the activation fragments are requested PF chunks ahead of their MFMAs, as in run_p)
+    constexpr int PF = DHW_APF == 0 ? 0 : (MT == 1 && DHW_APF == 3 ? 3 : 1), NB = PF + 1;
+    Frag<T> a[NB][MT];
+    auto request = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) a[slot][j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+      if (c < KT_) request(c);
 #pragma unroll
     for (int s = 0; s < KT_; ++s) {
       const int d = (s + ROT) % DE;
-      Frag<T> a[MT];
-#pragma unroll
-      for (int j = 0; j < MT; ++j) a[j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      if (PF == 0) request(0);
+      else if (s + PF < KT_) request((s + PF) % NB);
+      if (PF != 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) mma32(acc[i][j], q[d][i], a[j]);
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], q[d][i], a[s % NB][j]);
       const int nx = s + DE;   // position in the concatenated stream that goes into the freed slot
       if (nx < KT_) {
         load_chunk(d, nx);
@@ -267,9 +286,7 @@ struct WRing {
 #pragma unroll
         for (int i = 0; i < NT; ++i) q[d][i] = frag_load(nbase + ((size_t)i * nKTS + (nx - KT_)) * 512);
       }
-      const bool wrap = ++kc == KC;
-      aoff += wrap ? tap_step : 32 * ES;
-      kc = wrap ? 0 : kc;
+      if (PF != 0) __builtin_amdgcn_sched_barrier(0);
     }
     if (KTN_ != 0) { base = nbase; KT = KTN_; KTS = nKTS; }
   }
@@ -376,8 +393,11 @@ DHW_DEV void layernorm_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, 
 // One-barrier form for the bf16 kernels: per-wave partial sums of x and x^2 go out together and var = E[x^2] - mean^2
 // (fp32; the rows are O(1) residual-stream values over 192-384 channels, so the cancellation costs ~1e-6 relative, far
 // below the bf16 rounding of the result).  Saves one LDS round trip + barrier per LayerNorm.
-template <int MT, int NT, int WN, int ROWS>
-DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true) {
+struct NoHook { DHW_DEV void operator()() const {} };
+// mid(): called once between the partial-sum writes and the barrier — the place where a caller requests a slice of the next
+// stage's weight fragments, so that the request's issue time runs under the other waves' arrival at the barrier
+template <int MT, int NT, int WN, int ROWS, typename Mid = NoHook>
+DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true, Mid mid = Mid()) {
   const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -392,6 +412,7 @@ DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int 
       red[(WN + wn) * ROWS + row0 + j * 16 + l15] = q;
     }
   }
+  mid();
   lds_barrier();
   const float invn = 1.0f / (float)N;
 #pragma unroll
@@ -408,8 +429,8 @@ DHW_DEV void layernorm_rows_1pass(f32x4 (&acc)[NT][MT], float* red, int wn, int 
 
 // LayerNorm flavour by element type: the fp32 parity mode keeps the two-pass form (mean, then centred squares), bf16 the
 // one-barrier E[x^2] - mean^2 form.
-template <typename T, int MT, int NT, int WN, int ROWS>
-DHW_DEV void ln_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true) {
-  if constexpr (sizeof(T) == 4) layernorm_rows<MT, NT, WN, ROWS>(acc, red, wn, row0, lane, N, act);
-  else layernorm_rows_1pass<MT, NT, WN, ROWS>(acc, red, wn, row0, lane, N, act);
+template <typename T, int MT, int NT, int WN, int ROWS, typename Mid = NoHook>
+DHW_DEV void ln_rows(f32x4 (&acc)[NT][MT], float* red, int wn, int row0, int lane, int N, bool act = true, Mid mid = Mid()) {
+  if constexpr (sizeof(T) == 4) { mid(); layernorm_rows<MT, NT, WN, ROWS>(acc, red, wn, row0, lane, N, act); }
+  else layernorm_rows_1pass<MT, NT, WN, ROWS, Mid>(acc, red, wn, row0, lane, N, act, mid);
 }
