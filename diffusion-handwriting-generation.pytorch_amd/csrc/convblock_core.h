@@ -109,6 +109,10 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   static_assert(!ASYM || WM1 == 1, "the asymmetric tiling: blocks with one row group in conv1");
+#ifndef DHW_CONV_SPREAD
+#define DHW_CONV_SPREAD 0   // measured neutral (18.763 vs 18.764 ms, profiles/r05_spread_ab.log): off
+#endif
+  constexpr bool CSPREAD = DHW_CONV_SPREAD != 0 && sizeof(T) == 2;
   constexpr bool PPX = PP != 0;
   static_assert(!PPX || (TALL && WM1 == 2 && WN1 == 4 && CH == 0 && !ASYM && OCC == 1), "ping-pong: the 2 x 4 wave layouts of the tall tiles");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
@@ -203,8 +207,14 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
     acc_zero(acc);
     ringu.template run_s<MTG, 3 * UCH / 32>(acc, HS + (rowu0 + l15) * SHh + g * 8 * ES, SHh, KCh);
     STAMP(11);
+    // conv1's first weight fragments fly during this stage's epilogue.  DHW_CONV_SPREAD (round 5): requested in quarters BETWEEN its pieces — 758 vector
+    // instructions per wave, the block's longest epilogue — instead of as one burst in front of it (a wave sits in instruction issue until the CU's
+    // L1 path has accepted its whole request: enc_bc_core.h, DHW_ENC_SPREAD)
+    constexpr int FC1 = decltype(ring1)::template fill_chunks<KT1>(), FQ1 = (FC1 + 3) / 4;
+    const T* w1p = reinterpret_cast<const T*>(p.w_c1) + ((size_t)nt01 * KCin * 3 * 64 + lane) * 8;
     if (act1) {
-      fill1();   // flies during the epilogue
+      if constexpr (CSPREAD) { ring1.template fill_begin<KT1>(w1p); ring1.template fill_range<KT1, 0, FQ1>(); }
+      else fill1();   // flies during the epilogue
       ep1.load(p.b_c1, gam + p.f1, bet + p.f1, n1);
     }
     {
@@ -218,10 +228,13 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
           const int r = min(rowu0 + j * 16 + l15, RX - 1);   // (clamped: rows past RX are computed but never stored)
           acc[i][j] = round_to<T>(acc[i][j] + epu.bias[i] + load4(reinterpret_cast<const T*>(XR + r * SX) + nu + 16 * i));
         }
+      if constexpr (CSPREAD) { if (act1) ring1.template fill_range<KT1, FQ1, 2 * FQ1>(); }
       // (a 16-byte store covers the partner lane's `low` values too: its data depends, through the lane swap, on both lanes'
       // loads of the pair, so no store can be issued ahead of them)
       store_tiles<T, NTU, MTG>(lane, XR, SX, rowu0, nu, acc, keep, valid);
+      if constexpr (CSPREAD) { if (act1) ring1.template fill_range<KT1, 2 * FQ1, 3 * FQ1>(); }
       CB_SILU_TILES(NTU, MTG, acc);
+      if constexpr (CSPREAD) { if (act1) ring1.template fill_range<KT1, 3 * FQ1, FC1>(); }
       store_tiles<T, NTU, MTG>(lane, XS, SX, rowu0, nu, acc, keep, valid);
     }
     STAMP(12);

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const char* top = RT + l15 * S + g * 8 * ES;
 
   WRing<T, NT> ring;
+#ifndef DHW_TEXT_SPREAD
+#define DHW_TEXT_SPREAD 1
+#endif
+  constexpr bool TSPREAD = DHW_TEXT_SPREAD != 0;
+  constexpr int FC = WRing<T, NT>::template fill_chunks<KC>(), FQ = (FC + 3) / 4;
   EpiParams<NT> ep;
 
   // ---- s = FiLM1(style rows), t1 = FiLM2(token rows) -> LDS
@@ -166,9 +171,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 acc[NT][MTS];
     acc_zero(acc);
     ring.template run_s<MTS, KC>(acc, sop, S, KC);
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_kv8) + wlane);
+    // (DHW_TEXT_SPREAD: the K projection's first weight fragments in quarters between the tiles of the V^T scatter, not one burst in front of it)
+    if constexpr (TSPREAD) ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_kv8) + wlane);
+    else ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_kv8) + wlane);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+      if constexpr (TSPREAD) {
+        if (i == 0) ring.template fill_range<KC, 0, FQ>();
+        else if (i == 1) ring.template fill_range<KC, FQ, 2 * FQ>();
+        else if (i == 2) ring.template fill_range<KC, 2 * FQ, 3 * FQ>();
+      }
 #pragma unroll
       for (int j = 0; j < MTS; ++j) {
         const int key = j * 16 + l15;
@@ -176,6 +188,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) *reinterpret_cast<T*>(RV + (n0 + 16 * i + k) * SVT + key * ES) = from_f<T>(key < p.S5 ? v[k] : 0.f);
       }
+    }
+    if constexpr (TSPREAD) { static_assert(NT == 3, "three channel tiles per wave"); ring.template fill_range<KC, 3 * FQ, FC>(); }
     ep.load_bias(p.b_kv8, n0);
   }
   {  // ---- K = s Wk + bk, written over s once every wave has finished reading it
@@ -231,7 +245,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 acc[NT][MT];
     acc_zero(acc);
     ring.template run_s<MT, KC>(acc, top, S, KC);
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_tf1) + wlane);   // FFN half 0: flies during the LayerNorm
+    if constexpr (TSPREAD) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_tf1) + wlane); ring.template fill_range<KC, 0, FQ>(); }
+    else ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_tf1) + wlane);   // FFN half 0: flies during the LayerNorm
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -248,7 +263,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         acc[i][j] += ep.bias[i] + res;
       }
-    ln_rows<T, MT, NT, 8, BM>(acc, red, wave, 0, lane, DM);
+    if constexpr (TSPREAD) {
+      ring.template fill_range<KC, FQ, 2 * FQ>();
+      ln_rows<T, MT, NT, 8, BM>(acc, red, wave, 0, lane, DM, true, [&]() { ring.template fill_range<KC, 2 * FQ, 3 * FQ>(); });
+      ring.template fill_range<KC, 3 * FQ, FC>();
+    } else ln_rows<T, MT, NT, 8, BM>(acc, red, wave, 0, lane, DM);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -274,9 +293,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     acc_zero(acc);
     ep.load_bias(p.b_tf1 + hh * DM, n0);
     ring.template run_s<MT, KC>(acc, s2op, S, KC);
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_tf3) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
+    if constexpr (TSPREAD) ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_tf3) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
+    else ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_tf3) + (((size_t)ntile0 * 2 * KC + hh * KC) * 64 + lane) * 8, 2 * KC);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+      if constexpr (TSPREAD) {
+        if (i == 0) ring.template fill_range<KC, 0, FQ>();
+        else if (i == 1) ring.template fill_range<KC, FQ, 2 * FQ>();
+        else if (i == 2) ring.template fill_range<KC, 2 * FQ, 3 * FQ>();
+      }
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         f32x4 v = acc[i][j] + ep.bias[i];
@@ -284,6 +309,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int k = 0; k < 4; ++k) v[k] = silu_t<T>(v[k]);
         store4(reinterpret_cast<T*>(HID + (j * 16 + l15) * S) + n0 + 16 * i, v);
       }
+    }
+    if constexpr (TSPREAD) ring.template fill_range<KC, 3 * FQ, FC>();
     lds_barrier();
     ring.template run_s<MT, KC>(acc2, hop, S, KC);
     if (hh == 0) {
@@ -324,6 +351,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
   char* TL = XS + BM * SI;               // tl [BM][DMO]
   float* red = reinterpret_cast<float*>(TL + BM * SO);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+#ifndef DHW_TEXT_SPREAD
+#define DHW_TEXT_SPREAD 1
+#endif
+  constexpr bool TSPREAD = DHW_TEXT_SPREAD != 0;
   const int pair = blockIdx.x * PAIRS;
   const int npair = min(PAIRS, p.n - pair);          // (the last workgroup of an odd n holds one pair: its second half stays zero)
   const float* gam = p.film + (long)(pair / p.film_div) * p.film_bs;
@@ -332,6 +363,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
   const int wn = act ? wave : 0, ntile0 = wn * NT, n0 = ntile0 * 16 + 4 * g;
 
   WRing<T, NT, 24 / OCC> ring;
+  constexpr int FCO = WRing<T, NT, 24 / OCC>::template fill_chunks<KCO>(), FQO = (FCO + 3) / 4;   // ring slots a stage's first request fills, a quarter of them
   EpiParams<NT> ep;
   {  // text_out rows -> LDS through SiLU (text_dense's input activation, nn.py:165-175)
     const T* src = reinterpret_cast<const T*>(p.text_out) + (size_t)pair * p.Lt * DI;
@@ -364,14 +396,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
     acc_zero(acc);
     if (act) {
       ring.template run_s<MT, KCI>(acc, XS + l15 * SI + g * 8 * ES, SI, KCI);
-      ring.template fill_s<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)ntile0 * KCO * 64 + lane) * 8);   // K half
+      // (DHW_TEXT_SPREAD, round 5: the next stage's first weight fragments in quarters between the pieces of the epilogue, as enc_bc_core.h DHW_ENC_SPREAD)
+      if constexpr (TSPREAD) { ring.template fill_begin<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)ntile0 * KCO * 64 + lane) * 8); ring.template fill_range<KCO, 0, FQO>(); }
+      else ring.template fill_s<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)ntile0 * KCO * 64 + lane) * 8);   // K half
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i];
+      if constexpr (TSPREAD) ring.template fill_range<KCO, FQO, 2 * FQO>();
     }
-    ln_rows<T, MT, NT, WN, BM>(acc, red, wn, 0, lane, DMO, act);
+    if constexpr (TSPREAD) ln_rows<T, MT, NT, WN, BM>(acc, red, wn, 0, lane, DMO, act, [&]() { if (act) ring.template fill_range<KCO, 2 * FQO, 3 * FQO>(); });
+    else ln_rows<T, MT, NT, WN, BM>(acc, red, wn, 0, lane, DMO, act);
     if (act) {
+      if constexpr (TSPREAD) ring.template fill_range<KCO, 3 * FQO, FCO>();
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -393,9 +430,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
     if (act) {
       ep.load_bias(p.b_kv, n0);
       ring.template run_s<MT, KCO>(acc, lop, SO, KCO);
-      ring.template fill_s<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)(DMO / 16 + ntile0) * KCO * 64 + lane) * 8);   // V half
+      if constexpr (TSPREAD) ring.template fill_begin<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)(DMO / 16 + ntile0) * KCO * 64 + lane) * 8);
+      else ring.template fill_s<KCO>(reinterpret_cast<const T*>(p.w_kv) + ((size_t)(DMO / 16 + ntile0) * KCO * 64 + lane) * 8);   // V half
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i) {
+        if constexpr (TSPREAD) { if (i == 0) ring.template fill_range<KCO, 0, 2 * FQO>(); else if (i == NT - 1) ring.template fill_range<KCO, 2 * FQO, FCO>(); }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           const int r = j * 16 + l15, rr = r & 31;                       // rr: the token's position inside its pair
@@ -403,6 +442,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
           v += *reinterpret_cast<const f32x4*>(p.pb_k1 + (size_t)(rr < p.Lt ? rr : p.Lt - 1) * DMO + n0 + 16 * i);   // (clamped, not branched)
           store4(reinterpret_cast<T*>(XS + r * SO) + n0 + 16 * i, v);   // (the SiLU(text) tile is dead: two barriers ago)
         }
+      }
+      if constexpr (TSPREAD && NT == 1) ring.template fill_range<KCO, 2 * FQO, FCO>();
     }
     lds_barrier();
     copy_out(p.k1);
