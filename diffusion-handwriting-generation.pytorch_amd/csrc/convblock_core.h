@@ -109,6 +109,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   static_assert(!ASYM || WM1 == 1, "the asymmetric tiling: blocks with one row group in conv1");
+#ifndef DHW_CONV_FCX
+#define DHW_CONV_FCX 1
+#endif
 #ifndef DHW_CONV_SPREAD
 #define DHW_CONV_SPREAD 0   // measured neutral (18.763 vs 18.764 ms, profiles/r05_spread_ab.log): off
 #endif
@@ -377,10 +380,15 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   f32x4 acc[NT2][MT2];
   acc_zero(acc);
   if (act2) {
-    ring2.template run_s<MT2, CO / 32>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
+    const T* wsk = reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8;
+    // (DHW_CONV_FCX: conv_skip's first fragments requested under fc's MFMAs — run_n — instead of as one burst behind them)
+    constexpr bool FCX = SK && (DHW_CONV_FCX != 0) && CO / 32 <= decltype(ring2)::D && DHW_ABL == 0;
+    if constexpr (FCX) ring2.template run_n<MT2, CO / 32, KT1>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32, wsk);
+    else ring2.template run_s<MT2, CO / 32>(acc, H2 + (row02 + l15) * SH2 + g * 8 * ES, SH2, CO / 32);
     STAMP(6);
-    if constexpr (SK) ring2.template fill_s<KT1>(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8);
-    else ring2.fill(reinterpret_cast<const T*>(p.w_skip) + ((size_t)nt02 * KCin * 3 * 64 + lane) * 8, KCin * 3);
+    if constexpr (FCX) {}
+    else if constexpr (SK) ring2.template fill_s<KT1>(wsk);
+    else ring2.fill(wsk, KCin * 3);
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
 #pragma unroll

@@ -290,6 +290,53 @@ struct WRing {
     }
     if (KTN_ != 0) { base = nbase; KT = KTN_; KTS = nKTS; }
   }
+
+  // ---- a SHORT stage (KT_ <= D chunks, no refills of its own) followed by a long one: the next stage's fill rides under this
+  // stage's MFMAs instead of standing as one burst between the two main loops (the ConvBlock's fc -> conv_skip: KT_ = CO / 32 = 4-8
+  // chunks against 12-36).  Slot s takes the next stage's chunk s the moment this stage's chunk s is consumed; the slots this
+  // stage never used (KT_ .. ) take theirs alongside, spread over the steps.  The next stage then starts as after fill_s<KTN_>
+  // (chunk c in slot c, no rotation).  Same requests, same MFMA order: bit-identical.
+  template <int MT, int KT_, int KTN_>
+  DHW_DEV void run_n(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC, const T* __restrict__ nbase, int nkts = 0) {
+    static_assert(KT_ <= D, "run_n: the stage must fit the ring");
+    constexpr int ES = sizeof(T), DN = eff_depth<KTN_>();
+    constexpr int XTRA = DN > KT_ ? DN - KT_ : 0, PER = (XTRA + KT_ - 1) / KT_;
+    const int nKTS = nkts ? nkts : KTN_;
+    int aoff = 0, kc = 0;
+    const int tap_step = stride - (KC - 1) * 32 * ES;
+    constexpr int PF = DHW_APF == 0 ? 0 : (MT == 1 && DHW_APF == 3 ? 3 : 1), NB = PF + 1;
+    Frag<T> a[NB][MT];
+    auto request = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) a[slot][j] = frag_load(reinterpret_cast<const T*>(abase + j * 16 * stride + aoff));
+      const bool wrap = ++kc == KC;
+      aoff += wrap ? tap_step : 32 * ES;
+      kc = wrap ? 0 : kc;
+    };
+    auto next_chunk = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) q[c][i] = frag_load(nbase + ((size_t)i * nKTS + c) * 512);
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+      if (c < KT_) request(c);
+#pragma unroll
+    for (int s = 0; s < KT_; ++s) {
+      if (PF == 0) request(0);
+      else if (s + PF < KT_) request((s + PF) % NB);
+      if (PF != 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) mma32(acc[i][j], q[s][i], a[s % NB][j]);
+      if (s < DN) next_chunk(s);
+#pragma unroll
+      for (int e = 0; e < PER; ++e)
+        if (KT_ + s * PER + e < DN) next_chunk(KT_ + s * PER + e);
+      if (PF != 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    base = nbase; KT = KTN_; KTS = nKTS;
+  }
 };
 
 // one-shot form: fill + run
