@@ -361,6 +361,36 @@ DHW_DEV void attn_block_bf16(int lane, const Frag<bf16_t> (*qf)[(D + 31) / 32], 
         else mma32(o[u][t], vf[u][t][pp], pf[u][pp]);
       }
 }
+// One unit — 16 query rows of head h — against KB keys of the staged tiles starting at tile row `krow` (sample key index `kb`): the
+// building block of the key-split wave layout of enc_bc_core.h (DHW_ATT_KSPLIT), where the two waves of a row group share the
+// third head's keys, 32 each.  kt / vt: the staged K / V tiles ([keys][channels], row strides SK / SV bytes).
+template <int KB>
+DHW_DEV void attn_unit_bf16(int lane, const Frag<bf16_t> (&qf)[2], const char* kt, int SK, const char* vt, int SV, int h, int krow, int kb, int Lk,
+                            float& m, float& l, f32x4 (&o)[4]) {
+  const int l15 = lane & 15, g = lane >> 4;
+  const char* const ktu[1] = {kt + (krow + l15) * SK + h * 128};
+  const char* const vtu[1] = {vt + (krow + 4 * g + (l15 >> 2)) * SV + 8 * (l15 & 3) + h * 128};
+  float m1[1] = {m}, l1[1] = {l};
+  if (kb + KB > Lk) attn_block_bf16<64, KB, false, 1, true>(lane, &qf, ktu, SK, vtu, SV, kb, 0u, Lk, m1, l1, &o);
+  else attn_block_bf16<64, KB, false, 1, false>(lane, &qf, ktu, SK, vtu, SV, kb, 0u, Lk, m1, l1, &o);
+  m = m1[0];
+  l = l1[0];
+}
+
+// (m, l, o) <- the running-softmax state over the union of this wave's keys and another wave's (its state at ms: o as 4 x f32x4, then
+// max, then this lane's partial sum; maxima in log2 units as attn_block_bf16 keeps them).  One function, no implicit contraction: every
+// kernel that merges gets the same bits.  exp2(-inf) = 0: an empty partner state leaves this one unchanged (this one is never empty).
+DHW_DEV void attn_merge_state(float& m, float& l, f32x4 (&o)[4], const float* ms) {
+#pragma clang fp contract(off)
+  const float m1 = ms[16], l1 = ms[17];
+  const float mm = fmaxf(m, m1);
+  const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+  l = l * a0 + l1 * a1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = o[t] * a0 + *reinterpret_cast<const f32x4*>(ms + 4 * t) * a1;
+  m = mm;
+}
+
 // One KB-key block for the UMAX (1 or 2) units of a wave: unit u = head hs + u * HS, active when that head exists (the
 // second unit of a wave may not).  kt / vt: the staged tiles (row stride SK / SV bytes); head h lies h * 64 channels further:
 // columns of the K tile and of the bf16 V tile ([keys][channels]), rows of the fp32 V^T tile ([channels][keys]).

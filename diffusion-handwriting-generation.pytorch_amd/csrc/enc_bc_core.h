@@ -146,6 +146,24 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     constexpr int BUFB = KBS * SK + (VROW ? KBS * SV : DM * SV);   // one staged block: K tile, then V tile
     constexpr int QKS = qkv_stride<T, DM>();
     const int rg = wave % RG, hs = wave / RG;
+    // DHW_ATT_KSPLIT (round 5).  d = 192 with 64-row tiles: 4 row groups x 3 heads = 12 units on 8 waves — waves 0-3 ran heads 0 and 2, waves 4-7
+    // head 1 alone, and every key block lasted two units.  Here the two waves of a row group SHARE the third head's keys: wave (rg, 0) takes
+    // head 0 and keys [0, 32) of head 2 of every block, wave (rg, 1) head 1 and keys [32, 64) of head 2 — 1.5 units each — and the two
+    // partial (max, sum, output) states of head 2 are merged once behind the last block (the split-key combination of the running softmax).
+    // The 32-row tiles (2 row groups x 4 head slots, one of them idle) compute head 2 the same way — slot 2 the first halves, slot 3 the
+    // second — so that a row's arithmetic stays independent of the tile the launcher picks (a shard of a batch == the same samples inside
+    // it, bit for bit).  Against DHW_ATT_KSPLIT=0 the summation order of head 2's softmax differs: equal to fp32 rounding, not bit for bit.
+    // MEASURED NEUTRAL (17.959 vs 17.964 ms same-box, profiles/r05_spread_ab.log r5ad_ks; parity suite green with it on): the stage is bound by
+    // the SIMD's total softmax VALU work — 3 units per SIMD and block either way, ~1 kcycle of vector issue each — not by the longest wave.  Off.
+#ifndef DHW_ATT_KSPLIT
+#define DHW_ATT_KSPLIT 0
+#endif
+    constexpr bool KSPLIT = sizeof(T) == 2 && DHW_ATT_KSPLIT != 0 && H == 3 && (HS == 2 || HS == 4) && KBS == 64 && DB && PLFIX;
+    constexpr int SU = HS == 2 ? 1 : 0;                       // the state slot of a wave's share of head 2
+    const bool ks_full = HS == 2 || hs < 2;                   // this wave runs a whole head (slot 0: head hs)
+    const bool ks_part = HS == 2 || hs >= 2;                  // this wave runs one half of head 2's keys ..
+    const int ks_half = HS == 2 ? hs : hs - 2;                // .. this one
+    auto unit_head = [&](int u) { return !KSPLIT ? hs + u * HS : (HS == 2 ? (u == 1 ? 2 : hs) : (hs >= 2 ? 2 : hs)); };
     const T* qk = reinterpret_cast<const T*>(p.qk2);
     const T* ksrc = qk + (size_t)b * p.Lk * QKS + DM;
     const T* vsrc = VROW ? ksrc + DM : reinterpret_cast<const T*>(p.vt2) + (size_t)b * DM * p.lpadX;
@@ -180,7 +198,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
     f32x4 o[UMAX][4];
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
-      const int h = hs + u * HS;
+      const int h = unit_head(u);
       const T* qrow = qk + (size_t)(b * p.Lk + m0 + rg * 16 + l15) * QKS + (h < H ? h : 0) * 64 + 8 * g;
       qf[u][0] = frag_load(qrow);
       qf[u][1] = frag_load(qrow + 32);
@@ -213,6 +231,11 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
         if (!more && act) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_d2) + wlane); ring.template fill_range<KC, 0, 2 * FQ>(); }
       }
       if (ib < 3) STAMP(26 + 2 * ib);
+      if constexpr (KSPLIT) {
+        if (ks_full) attn_unit_bf16<KBS>(lane, qf[0], KT, SK, VT, SV, hs, 0, kb, p.Lk, mr[0], lr[0], o[0]);
+        const int kh = (KBS / 2) * ks_half;   // (wave-uniform; a half past the end of the sequence is skipped: its state stays empty)
+        if (ks_part && kb + kh < p.Lk) attn_unit_bf16<KBS / 2>(lane, qf[SU], KT, SK, VT, SV, 2, kh, kb + kh, p.Lk, mr[SU], lr[SU], o[SU]);
+      } else
       attn_units<T, KBS, false, UMAX>(lane, qf, KT, SK, VT, SV, hs, HS, H, kb, 0u, p.Lk, mr, lr, o);
       if (ib < 3) STAMP(27 + 2 * ib);
       if (more) {
@@ -242,10 +265,24 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
       PL = reinterpret_cast<float*>(((ib - 1) & 1) ? R2 + 2 * BM * S + 2 * 8 * BM * sizeof(float) : R2 + BUFB);
       cp.template store<DM>(PL, tid);
     }
+    if constexpr (KSPLIT) {
+      // head 2: the wave with the second halves hands its partial state to the one with the first halves through the staging buffer the last
+      // block did not use (free since the previous iteration's barrier; the parameter block sits behind both buffers: PLFIX)
+      float* MS = reinterpret_cast<float*>(R2 + (((ib - 1) & 1) ? 0 : BUFB)) + (rg * 64 + lane) * 20;
+      static_assert((size_t)RG * 64 * 20 * sizeof(float) <= (size_t)BUFB, "merge scratch inside a staging buffer");
+      if (ks_part && ks_half == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(MS + 4 * t) = o[SU][t];
+        MS[16] = mr[SU];
+        MS[17] = lr[SU];
+      }
+      lds_barrier();
+      if (ks_part && ks_half == 0) attn_merge_state(mr[SU], lr[SU], o[SU], MS);
+    }
     WST(1);
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
-      const int h = hs + u * HS;
+      const int h = !KSPLIT ? hs + u * HS : (u == SU && ks_part) ? (ks_half == 0 ? 2 : H) : hs;   // (H: nothing to store)
       float l = lr[u];
       l = xg_sum(l);
       const float inv = 1.0f / l;

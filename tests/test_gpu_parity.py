@@ -432,6 +432,36 @@ def test_two_text_pairs_per_workgroup_give_the_same_bits():
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("L", [488, 168, 48, 264])
+def test_three_head_layer_on_both_row_tiles_matches_oracle(L, monkeypatch):
+    """enc3 (d = 192, three heads: 12 (row group, head) units on 8 waves) on 64-row and on 32-row tiles.  The bench batch picks 64 rows by itself
+    (B * ceil(L/2 / 64) >= 256); here the tile is forced at B = 2 so that the oracle finishes in seconds.  Key counts: 244 (four blocks, the last
+    one partial), 84 (20 keys in the last block), 24 (a single partial block), 132 (the last block holds 4 keys).  The enc3 tap isolates the layer;
+    eps / pen bound what reaches the output.  Also the test of -DDHW_ATT_KSPLIT=1 (enc_bc_core.h: the two waves of a row group share the third
+    head's keys, 32 of every 64-key block each, and merge their partial softmax states; measured neutral, off by default): the key counts are the
+    cases of its skip / merge paths, and it passed with the switch on (gpurun_out/r5ad_ks)."""
+    B, Lt = 2, 9
+    inp = spec.synthetic_inputs(B, L, Lt, seed=900 + L, pad=1)
+    sg = torch.tensor([[0.3], [0.8]])
+    taps = {}
+    with torch.no_grad():
+        e_ref, p_ref = ref_cpu.forward(_sd(2), torch.from_numpy(inp["strokes"]), torch.from_numpy(inp["text"]), sg,
+                                       torch.from_numpy(inp["style"]), taps=taps)
+    seen = {}
+    for prec, bm in (("bf16", "64"), ("bf16", "32"), ("fp32", "64")):
+        monkeypatch.setenv("DHW_ENC_BM192", bm)   # (read at every launch)
+        m = get_model(2, prec)
+        eps, pen = fwd(m, inp, sg)
+        ref = taps["enc3"].numpy()
+        got = m.debug_read("enc3").numpy().reshape(ref.shape)
+        tol = TOL[prec]["tap"] if prec == "fp32" else TOL[prec]["tap_rel"] * np.abs(ref).max()
+        assert np.abs(got - ref).max() < tol, (prec, bm, np.abs(got - ref).max(), tol)
+        assert np.abs(eps - e_ref.numpy()).max() < TOL[prec]["eps"] and np.abs(pen - p_ref.numpy()).max() < TOL[prec]["pen"]
+        seen[prec, bm] = (got.copy(), eps.copy())
+    # a row's arithmetic does not depend on the tile the launcher picks (what makes a shard equal to the same samples inside a batch)
+    assert np.array_equal(seen["bf16", "64"][0], seen["bf16", "32"][0]) and np.array_equal(seen["bf16", "64"][1], seen["bf16", "32"][1])
+
+
 def test_long_sequence_config_matches_oracle():
     """BASELINE configs[3] shape class (L=1000, 62 tokens) with a short schedule: exercises multi-block attention
     (L/2 = 500 keys), several row tiles per sample at every level and the T-generalised schedule."""
