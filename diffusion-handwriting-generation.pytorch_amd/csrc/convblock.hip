@@ -80,11 +80,17 @@ hipError_t convblock_init() {
   return hipSuccess;
 }
 
+// workgroups that fill the device in one round (experiments: DHW_CONV_WGS, e.g. 128 for a half batch that shares the CUs with the other half's kernels)
+static long conv_wgs() {
+  const char* e = getenv("DHW_CONV_WGS");
+  return e ? atol(e) : 256;
+}
+
 // 46-row tiles for the widest blocks (L/4 level) when the 62-row tiling leaves CUs idle and the finer one still fits one round
 static bool use_bm48(const ConvBlockParams& p) {
   if (const char* e = getenv("DHW_CONV_BM")) return atoi(e) == 48;
   const long t64 = (long)p.B * ((p.L + 61) / 62), t48 = (long)p.B * ((p.L + 45) / 46);
-  return t64 < 256 && t48 <= 256 && t48 > t64;
+  return t64 < conv_wgs() && t48 <= conv_wgs() && t48 > t64;
 }
 
 // 32-row tiles with conv1 over 48 rows (TIGHT = 2) for the widest blocks when they fill the CUs in one round where the 46-row
@@ -93,7 +99,7 @@ static bool use_asym32(const ConvBlockParams& p) {
   static const bool on = !(getenv("DHW_CONV_ASYM") && atoi(getenv("DHW_CONV_ASYM")) == 0);
   if (!on || getenv("DHW_CONV_BM")) return false;
   const long t32 = (long)p.B * ((p.L + 31) / 32), t46 = (long)p.B * ((p.L + 45) / 46);
-  return t32 <= 256 && t32 > t46;
+  return t32 <= conv_wgs() && t32 > t46;
 }
 
 // DHW_CONV_PP: bit 0 = enc1-type tall tiles (126 rows x 128 channels), bit 1 = dec1-type (fused input stage), run with their row
@@ -114,7 +120,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
     static const bool tight_ok = !(getenv("DHW_CONV_TIGHT") && atoi(getenv("DHW_CONV_TIGHT")) == 0);
     auto tight = [&](int bm) { return tight_ok && (p.L + bm - 5) / (bm - 4) == (p.L + bm - 3) / (bm - 2); };
     if (p.Cout == 128 && p.Cin == 192 && p.up_cin == 128) {
-      const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
+      const bool big = (long)p.B * ((p.L + 61) / 62) > conv_wgs() && lds_bytes<bf16_t, 128, 128>(p.Cin, p.up_cin) <= 160 * 1024;
       if (big && (conv_pp() & 2)) return tight(128) ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 1, 1>(p, st) : launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 0, 1>(p, st);
       if (big && tight(128)) return launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192, 1>(p, st);
       return big ? launch_t<bf16_t, 128, 128, 8, 1, 192, 0, 192>(p, st) : launch_t<bf16_t, 64, 128, 8, 1, 192, 0, 192>(p, st);
@@ -131,7 +137,7 @@ hipError_t launch_convblock(int prec, const ConvBlockParams& p_in, hipStream_t s
     const bool sk = !rt && p.Cin == enc_cin(p.Cout);   // an encoder block: static contraction lengths
     switch (p.Cout) {
       case 128: {   // full-resolution blocks: 126-row tiles keep the grid within one round of workgroups (one 8-wave WG per CU)
-        const bool big = (long)p.B * ((p.L + 61) / 62) > 256 && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
+        const bool big = (long)p.B * ((p.L + 61) / 62) > conv_wgs() && lds_bytes<bf16_t, 128, 128>(p.Cin) <= 160 * 1024 &&
                          !(getenv("DHW_CONV_BM") && atoi(getenv("DHW_CONV_BM")) == 64);
         if (getenv("DHW_CONV_OCC") && atoi(getenv("DHW_CONV_OCC")) == 2 && sk && lds_bytes<bf16_t, 64, 128>(p.Cin) <= 80 * 1024)
           return launch_t<bf16_t, 64, 128, 8, 2, 0, 0, 128>(p, st);
