@@ -187,10 +187,14 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   constexpr int RINGA = sizeof(T) == 4 ? 12 : (DM == 384 && BM == 16 ? DHW_RINGA384 : 24);
   typedef WRing<T, NT, (XS ? XDE * NT : RINGA), (XS ? XDE : (RINGA + NT - 1) / NT)> RingT;
   RingT ring;
+#ifndef DHW_ENC_QALT
+#define DHW_ENC_QALT 1
+#endif
 #ifndef DHW_ENC_SPREAD
-#define DHW_ENC_SPREAD 3   // bit 0: enc_bc's stages (enc_bc_core.h), bit 1: enc_a's
+#define DHW_ENC_SPREAD 11  // bit 0: enc_bc's stages (enc_bc_core.h), bit 1: enc_a's
 #endif
   constexpr bool SPREADA = sizeof(T) == 2 && (DHW_ENC_SPREAD & 2) != 0 && !XS;
+  constexpr bool SPREADQ = sizeof(T) == 2 && (DHW_ENC_SPREAD & 8) != 0 && !XS && MT > 1;   // bit 3: the q / k / v chunks of the multi-row-tile layouts
   constexpr int FCHA = RingT::template fill_chunks<KC>(), FQA = (FCHA + 3) / 4;
   EpiParams<NT> ep;
   ENC_STAMP(0);
@@ -401,6 +405,10 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       if constexpr (SPREADA && MT == 1) {
         // (the single-row-tile form stores straight from the accumulators below: its few VALU + store instructions go between the request's halves)
         if (chunk < 2) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); ring.template fill_range<KC, 0, 2 * FQA>(); }
+      } else if constexpr (SPREADQ) {
+        // (several row tiles per wave — the 64- / 32-row tiles of d = 192 / 256: the chunk goes out through the LDS staging tile; the next chunk's
+        // request in quarters around the pieces of that path, DHW_ENC_SPREAD bit 3)
+        if (chunk < 2) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); ring.template fill_range<KC, 0, FQA>(); }
       } else if constexpr (!XS) { if (chunk < 2) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_qkv2) + (size_t)(chunk + 1) * DM * DM + wlane); }
     }
     if (rows_out && MT == 1) {
@@ -415,7 +423,14 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
       ENC_STAMP(5 + chunk);
       return;
     }
-    lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V^T) is free: every wave is past its readers
+    // DHW_ENC_QALT (round 5, bf16): the chunks alternate between TWO staging tiles — q and v through the q1 / a1 tile, k through the text K tile
+    // (dead since the cross-attention) — so the only barrier a chunk needs is the one between its LDS stores and its copy-out: the tile a chunk
+    // writes was last read two chunks (one barrier) earlier; q's tile by dense1's main loop, in front of the LayerNorm's barriers.  3 barriers
+    // instead of 6 for the three chunks.
+    constexpr bool QALT = sizeof(T) == 2 && DHW_ENC_QALT != 0 && VROW;
+    char* const QT = QALT && chunk == 1 ? m.KT : QR;
+    static_assert(!QALT || (size_t)BM * tile_stride<T>(DM) <= enc_a_text_kv_bytes<T, DM, BM>(), "a staging tile inside the text K / V tiles");
+    if constexpr (!QALT) lds_barrier();   // the staging tile (q1/a1 region, or x2+q1 regions for V^T) is free: every wave is past its readers
     if (rows_out) {
       // q2 / k2 (/ v2) chunk -> LDS tile [row][DM] -> coalesced rows of the [.., QKS] buffer
       if (act) {
@@ -423,10 +438,13 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
         for (int i = 0; i < NT; ++i)
 #pragma unroll
           for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
-        enc_store_tiles<T, NT, MT>(lane, QR, S, row0, n0 + opaque, acc);
+        if constexpr (SPREADQ) { if (chunk < 2) ring.template fill_range<KC, FQA, 2 * FQA>(); }
+        enc_store_tiles<T, NT, MT>(lane, QT, S, row0, n0 + opaque, acc);
+        if constexpr (SPREADQ) { if (chunk < 2) ring.template fill_range<KC, 2 * FQA, 3 * FQA>(); }
       }
       lds_barrier();
-      tile_copy_out<T>(QR, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);
+      tile_copy_out<T>(QT, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);
+      if constexpr (SPREADQ) { if (act && chunk < 2) ring.template fill_range<KC, 3 * FQA, FCHA>(); }
     } else if constexpr (!VROW) {
       // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2
       constexpr int SV = BM * ES + 16;

@@ -118,7 +118,7 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
 
   WRing<T, NT, RING, RDMAX> ring;
 #ifndef DHW_ENC_SPREAD
-#define DHW_ENC_SPREAD 3   // bit 0: this kernel's stages, bit 1: enc_a's (enc_a_core.h)
+#define DHW_ENC_SPREAD 11  // bit 0: this kernel's stages, bit 1: enc_a's (enc_a_core.h)
 #endif
   constexpr bool SPREAD = sizeof(T) == 2 && (DHW_ENC_SPREAD & 1) != 0;
   constexpr bool SPREAD_ATT = sizeof(T) == 2 && (DHW_ENC_SPREAD & 4) != 0 && !DHW_ENC_EARLYFILL && !DHW_ENC_XSTREAM;   // bit 2: the dense stage's request around the last key block
