@@ -9,7 +9,9 @@
 #include "dhw_kernels.h"
 
 // diagnostic stage stamps (100 MHz s_memrealtime), only when the caller passes a buffer
-#define ENC_STAMP(slot) DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, slot, __builtin_amdgcn_s_memrealtime())
+// (p.dbg bit 2, tools/bench_encw a: the same slots per wave, in shader cycles, where enc_bc keeps its per-wave timeline)
+#define ENC_STAMP(slot) do { DHW_STAMP_IF(p.stamps && blockIdx.x == 0 && threadIdx.x == 0, slot, __builtin_amdgcn_s_memrealtime()); \
+                             DHW_STAMP_IF(p.stamps && (p.dbg & 4) && blockIdx.x == 0 && (threadIdx.x & 63) == 0, 64 + (threadIdx.x >> 6) * 32 + (slot), __builtin_amdgcn_s_memtime()); } while (0)
 
 template <typename T, int BM>
 DHW_DEV void stage_rows(char* dst, int S, const T* src, int C, int b, int L, int m0, int tid, int nthreads) {
@@ -153,13 +155,13 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   // GEMM stages: every wave covers all BM rows and 1/WN of the channels, so no two waves stream the same weight
   // fragments (row groups would re-fetch them: the L2 -> CU weight stream is what bounds these kernels).  DM = 192 has
   // 12 channel tiles: 6 waves take 2 each, the other 2 waves only join the barriers (and the attention stage).
-  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;
+  constexpr int WN = (DM % 128 == 0) ? 8 : (sizeof(T) == 4 ? 6 : DHW_WN192), WM = (DM % 128 == 0 || sizeof(T) == 4) ? 1 : DHW_WM192;
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   static_assert(NT * WN * 16 == DM, "channel tiles must divide over the waves");
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const bool act = WN == 8 || wave < WN;
-  const int wm = 0, wn = act ? wave : 0;
+  const bool act = WN * WM == 8 || wave < WN * WM;
+  const int wm = act ? wave / WN : 0, wn = act ? wave % WN : 0;
   const int S = tile_stride<T>(DM);
   char* XR = m.XR;
   char* QR = m.QR;

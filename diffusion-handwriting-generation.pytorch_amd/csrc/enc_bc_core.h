@@ -77,6 +77,9 @@ constexpr bool bc_params_fixed() { return lds_bc_tiles<T, DM, BM>() + enc_bc_par
 template <typename T, int DM, int BM>
 constexpr size_t lds_bc_bytes() { return lds_bc_tiles<T, DM, BM>() + (bc_params_fixed<T, DM, BM>() ? enc_bc_param_bytes<T, DM>() : 0); }
 
+#ifndef DHW_RING192
+#define DHW_RING192 12   // weight-ring fragments of the d = 192, 64-row variant (4 waves x 3 tiles: 12 accumulators twice in the FFN stages)
+#endif
 // NEXT: 0, or the EncChain mode compiled into this variant (DN = width of the chained layer)
 template <typename T, int DM, int BM, int NEXT>
 constexpr size_t lds_bc_chain_bytes() {
@@ -94,15 +97,15 @@ constexpr size_t lds_a_bytes() { return (size_t)2 * BM * tile_stride<T>(DM) + 2 
 template <typename T, int DM, int BM, int NEXT = 0, typename P, typename X>
 DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, char* smem) {
   constexpr int ES = sizeof(T);
-  constexpr int WN = (DM % 128 == 0) ? 8 : 6, WM = 1;   // as in enc_a_body: all rows per wave, channels split over WN waves
+  constexpr int WN = (DM % 128 == 0) ? 8 : (sizeof(T) == 4 ? 6 : DHW_WN192), WM = (DM % 128 == 0 || sizeof(T) == 4) ? 1 : DHW_WM192;   // as in enc_a_body: all rows per wave, channels split over WN waves
   constexpr int MT = BM / WM / 16, NT = DM / WN / 16, H = DM / 64, KC = DM / 32;
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream (gemm_core.h, run_x); the fp32 parity mode keeps run_s + fill_s
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream
-  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 ? (BM >= 32 ? 15 : DHW_RING384) : 24)), RDMAX = XS ? XDE : (RING + NT - 1) / NT;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill)
+  constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 ? (BM >= 32 ? 15 : DHW_RING384) : (DM == 192 && NT == 3 && BM == 64 ? DHW_RING192 : 24))), RDMAX = XS ? XDE : (RING + NT - 1) / NT;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill; d = 192 as 4 waves x 3 tiles on 64 rows: the whole stage, 6 chunks — 8 slots spill)
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const bool act = WN == 8 || wave < WN;   // (DM = 192: waves 6, 7 own no channels in the GEMM stages)
-  const int wm = 0, wn = act ? wave : 0;
+  const bool act = WN * WM == 8 || wave < WN * WM;   // (DM = 192, 6 x 1: waves 6, 7 own no channels in the GEMM stages)
+  const int wm = act ? wave / WN : 0, wn = act ? wave % WN : 0;
   const int S = tile_stride<T>(DM);
   char* R1 = smem;               // a2, later SiLU(x3)
   char* R2 = R1 + BM * S;        // x3

@@ -152,6 +152,14 @@ struct WRing {
 #ifndef DHW_APF
 #define DHW_APF 3
 #endif
+#ifndef DHW_WM192
+#define DHW_WM192 1   // row groups of the d = 192 layout (experiment: 2 with DHW_WN192=4: 2 x 4 waves of 3 channel tiles x half the rows, weights fetched twice)
+#endif
+#ifndef DHW_WN192
+#define DHW_WN192 6   // waves that own channels of a d = 192 EncoderLayer stage: 12 tiles of 16 as 6 waves x 2.  4 waves x 3 (one per SIMD; every channel wave
+                      // reads the whole activation tile from LDS, and 6 x 2 puts two channel waves on SIMDs 0 / 1, one on 2 / 3) measured -0.11 %, -0.28 %
+                      // and +0.1 % on three boxes: not adopted; 2 row groups x 4 (-DDHW_WM192=2, weights fetched twice) -0.05 % (profiles/r05_spread_ab.log)
+#endif
   template <int MT, int KT_, int PF>
   DHW_DEV void run_p(f32x4 (&acc)[NT][MT], const char* abase, int stride, int KC) {
     if constexpr (DHW_EPI_PRIO != 0) __builtin_amdgcn_s_setprio(0);

@@ -1,6 +1,6 @@
 // bench_encw.cpp — per-wave timeline of one enc_bc workgroup (diagnostic build of enclayer.hip with -DDHW_STAMPS): shader-clock
 // stamps of all 8 waves of workgroup 0 at the phase boundaries inside the stages (csrc/enclayer.hip, WST slots).
-// usage: bench_encw [d=384] [Lk=61]
+// usage: bench_encw [d=384] [Lk=61] [a]   (a: the first half, enc_a, instead of enc_bc)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +52,35 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
   }
   std::vector<unsigned long long> h(NS);
+  if (argc > 3 && argv[3][0] == 'a') {
+    // the first half alone (enc_a_core.h, ENC_STAMP slots per wave: p.dbg bit 2)
+    CK(hipMemset(stamps, 0, NS * 8));
+    p.dbg = 4;
+    CK(launch_enclayer(PREC_BF16, p, 0, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(h.data(), stamps, NS * 8, hipMemcpyDeviceToHost));
+    const int order[15] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 12, 5, 13, 6, 14, 7};
+    const char* an[15] = {"start", "staged", "q1.run", "q1.epi", "bar", "xatt+bar", "d1.run", "ln.epi", "x2st+bar", "q.run", "q.end", "k.run", "k.end", "v.run", "v.end"};
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < 8; ++w) if (h[64 + w * 32] && h[64 + w * 32] < t0) t0 = h[64 + w * 32];
+    printf("enc_a d=%d Lk=%d: per-wave stamps of workgroup 0 [cycles since the first wave's start / 1000]\n%-10s", d, Lk, "slot");
+    for (int w = 0; w < 8; ++w) printf("   w%d  ", w);
+    printf("  max-min  d(max)\n");
+    double prevmax = 0;
+    for (int k = 0; k < 15; ++k) {
+      printf("%-10s", an[k]);
+      double mn = 1e30, mx = 0;
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long v = h[64 + w * 32 + order[k]];
+        const double t = v ? (double)(v - t0) / 1000.0 : -1;
+        if (v) { mn = t < mn ? t : mn; mx = t > mx ? t : mx; }
+        printf(" %6.2f", t);
+      }
+      printf("   %6.2f  %6.2f\n", mx - mn, mx - prevmax);
+      prevmax = mx;
+    }
+    return 0;
+  }
   CK(hipMemcpy(h.data(), stamps, NS * 8, hipMemcpyDeviceToHost));
   const char* names[25] = {"start", "att.end", "a2+fill", "bar17", "dense.run", "f1.fill", "bias+res", "ln", "film.st", "bar19",
                            "ffn1a.run", "f2a.fill", "silu.st", "bar", "ffn2a.run", "fill+bar", "ffn1b.run", "f2b.fill", "silu.st", "bar", "ffn2b.run", "(bar)", "res", "ln", "end"};
