@@ -180,7 +180,14 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #ifndef DHW_ENC_EARLYFILL
 #define DHW_ENC_EARLYFILL 0   // measured 19.13 vs 19.08 ms (profiles/r04_earlyfill_ab.log): the prefetch queues in front of the K / V block the attention waits for
 #endif
-  constexpr bool EARLYA = sizeof(T) == 2 && DHW_ENC_EARLYFILL;
+  // DHW_ENC_EARLYA (round 5): the dense stage's first weight fragments requested in the q1 epilogue, IN FRONT of the cross attention — here, unlike in
+  // enc_bc (DHW_ENC_EARLYFILL, r4: slower), no K / V loads follow them: the text K / V tiles were staged at the top of the kernel, so the request
+  // rides under the attention's LDS / MFMA / softmax work instead of standing as one burst between the attention and its barrier.
+  // MEASURED: 17.466 vs 17.454 ms without (profiles/r05_spread_ab.log, r5am): no gain — the attention's own LDS traffic and the request share the wave's issue.  Off.
+#ifndef DHW_ENC_EARLYA
+#define DHW_ENC_EARLYA 0
+#endif
+  constexpr bool EARLYA = sizeof(T) == 2 && (DHW_ENC_EARLYFILL || (DHW_ENC_EARLYA && !(DM == 384 && BM >= 32)));   // (d = 384 on 32-row tiles: the ring's registers across the attention spill)
   constexpr bool XS = sizeof(T) == 2 && DHW_ENC_XSTREAM && !(DM == 384 && BM >= 32);   // (d = 384 with 32-row tiles: two accumulator rows + the ring spill)   // cross-stage weight stream with whole-stage rings (gemm_core.h, run_x)
   constexpr int XDE = KC <= 8 ? KC : 8;   // ring depth (chunks) of the cross-stage stream: a whole stage at d = 192 / 256, 8 of 12 chunks at d = 384
 #ifndef DHW_RINGA384
@@ -271,15 +278,16 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     ring.template run_s<MT, KC>(acc, xop, S, KC);
     ENC_STAMP(8);
     if constexpr (PLDS) ep.lds_bias(PL, n0);
+    // the dense stage's first weight fragments: requested in front of the cross attention (the vector-memory path is idle during
+    // it), not behind it — in halves around the q1 tile's stores
+    if constexpr (EARLYA) { ring.template fill_begin<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane); ring.template fill_range<KC, 0, 2 * FQA>(); }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] += ep.bias[i] + pb[i][j];
     enc_store_tiles<T, NT, MT>(lane, QR, S, row0, n0, acc);
     ENC_STAMP(9);
-    // the dense stage's first weight fragments: requested in front of the cross attention (the vector-memory path is idle during
-    // it), not behind it — see enc_bc_core.h, DHW_ENC_EARLYFILL
-    if constexpr (EARLYA) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_d1) + wlane);
+    if constexpr (EARLYA) ring.template fill_range<KC, 2 * FQA, FCHA>();
   }
   lds_barrier();
   ENC_STAMP(2);
