@@ -451,10 +451,18 @@ struct PadMask {
         tok[4 * t + r] = trow[key < Lk ? key : Lk - 1];
       }
   }
+  // LAZY: the compares stay HERE.  hipcc otherwise evaluates them right behind the loads — s_waitcnt vmcnt(7) .. vmcnt(0) in front of the caller's
+  // first barrier, i.e. a wait for everything requested before them, the first stage's weights included.  Costs the 16 registers of the ids
+  // until then (the fp32 parity kernels, at their register limit, keep the eager form).
+  template <bool LAZY = false>
   DHW_DEV unsigned bits() const {
     unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < KB / 4; ++i) m |= (tok[i] == 0 ? 1u : 0u) << i;
+    for (int i = 0; i < KB / 4; ++i) {
+      int64_t t = tok[i];
+      if constexpr (LAZY) asm volatile("" : "+v"(t));
+      m |= (t == 0 ? 1u : 0u) << i;
+    }
     return m;
   }
 };

@@ -221,10 +221,37 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   const T* v1s = reinterpret_cast<const T*>(p.vt1) + (VROW ? (size_t)b * p.Lt * DM : (size_t)b * DM * p.lpadT);   // v1 [Lt][DM] / V^T [DM][lpadT]
   constexpr bool PLDS = enc_plds<T>();
   const float* PL = m.PL;   // [b_q1 | b_d1 | gamma1 | beta1 | b_qkv2 x 3], DM floats each
+  // DHW_ENC_KVLATE (round 5, bf16): the text K / V tiles are needed only behind q1, so they are requested BEHIND the q1 weights and written to LDS
+  // behind the q1 stage: the kernel (or, chained behind a ConvBlock / an enc_bc, this half) starts its first GEMM after ONE memory round trip —
+  // parameters + x tile, with the weights right behind them — instead of two (tiles, then weights requested once the tiles had been stored).
+  // MEASURED: 19.284 ms against 19.239 without and 19.270 for the build before (profiles/r05_spread_ab.log, r5an): no gain — the bytes through the CU's L1 path
+  // are the same and that path, not the number of round trips, sets the start-up time.  Off.
+#ifndef DHW_ENC_KVLATE
+#define DHW_ENC_KVLATE 0
+#endif
+  constexpr bool KVLATE = sizeof(T) == 2 && DHW_ENC_KVLATE != 0;
+  const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
+  PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
+  struct KVRegs { CopyRegs<UK> ck; CopyRegs<UV> cv; };
+  KVRegs kv_late;   // (KVLATE: alive across the q1 stage)
+  auto kv_store = [&](KVRegs& kv) {
+    CopyRegs<UK>& ck = kv.ck;
+    CopyRegs<UV>& cv = kv.cv;
+    ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); },
+             [&](int id) { return id / CPR < p.Lt; });
+    if constexpr (VROW)
+      cv.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(VT + r * SVC + cc * 16); },
+               [&](int id) { return id / CPR < p.Lt; });
+    else
+      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
+                  [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
+  };
   {
+    KVRegs kv_now;
+    KVRegs& kv = [&]() -> KVRegs& { if constexpr (KVLATE) return kv_late; else return kv_now; }();
+    CopyRegs<UK>& ck = kv.ck;
+    CopyRegs<UV>& cv = kv.cv;
     CopyRegs<UX> cx;
-    CopyRegs<UK> ck;
-    CopyRegs<UV> cv;
     ParamStage<7> cp;
     if constexpr (PLDS) {
       cp.template load<DM>(tid, p.b_q1, p.b_d1, gam + p.f1, bet + p.f1, p.b_qkv2, p.b_qkv2 + DM, p.b_qkv2 + 2 * DM);
@@ -233,6 +260,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     if (p.x)
       cx.load(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
                                                 return reinterpret_cast<const uint4*>(xs + (size_t)(b * p.Lk + (m0 + r < p.Lk ? m0 + r : p.Lk - 1)) * DM + cc * EPV); });
+    if constexpr (KVLATE) { if (act) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane); }
     ck.load(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR;
                                                return reinterpret_cast<const uint4*>(k1s + (size_t)(r < p.Lt ? r : p.Lt - 1) * DM + cc * EPV); });
     if constexpr (VROW)
@@ -244,23 +272,14 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     if (p.x)
       cx.store(BM * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(XR + r * S + cc * 16); },
                [&](int id) { return m0 + id / CPR < p.Lk; });
-    ck.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(KT + r * SKC + cc * 16); },
-             [&](int id) { return id / CPR < p.Lt; });
-    if constexpr (VROW)
-      cv.store(KBC * CPR, tid, 512, [&](int id) { const int r = id / CPR, cc = id - r * CPR; return reinterpret_cast<uint4*>(VT + r * SVC + cc * 16); },
-               [&](int id) { return id / CPR < p.Lt; });
-    else
-      cv.store_to(DM * PPR, tid, 512, [&](int id, const uint4& v) { const int ch = id / PPR, part = id - ch * PPR; vt_store_piece<T>(VT + ch * SVC, part, v); },
-                  [&](int id) { return (id % PPR + 1) * EPV <= p.lpadT; });
+    if constexpr (!KVLATE) kv_store(kv);
     if constexpr (PLDS) cp.template store<DM>(m.PL, tid);
   }
-  const int64_t* trow = p.text ? p.text + (size_t)b * p.Lt : nullptr;
-  PadMask<KBC> pad;   // key-padding mask of the first block: requested here, used after q1
   pad.load(lane, trow, 0, p.Lt);
   // the q1 weights are requested BEHIND the staging loads: a wave's loads complete in order and the L1 miss queue is
   // shared, so a 24 KB-per-wave prefetch in front of them delays the tiles everything waits for
   if (act) {
-    ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane);
+    if constexpr (!KVLATE) ring.template fill_s<KC>(reinterpret_cast<const T*>(p.w_q1) + wlane);
     if constexpr (!PLDS) ep.load_bias(p.b_q1, n0);
   }
   lds_barrier();
@@ -289,6 +308,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     ENC_STAMP(9);
     if constexpr (EARLYA) ring.template fill_range<KC, 2 * FQA, FCHA>();
   }
+  if constexpr (KVLATE) kv_store(kv_late);
   lds_barrier();
   ENC_STAMP(2);
 
@@ -312,7 +332,7 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
     }
     for (int kb = 0; kb < p.Lt; kb += KBC) {
       if (kb) pad.load(lane, trow, kb, p.Lt);
-      const unsigned padbits = pad.bits();
+      const unsigned padbits = pad.template bits<sizeof(T) == 2>();
       if (kb) {
         attn_stage_kv<T, KBC>(KT, SK, VT, SV, k1s, DM, v1s, VROW ? DM : p.lpadT, DM, kb, p.Lt, tid, 512);
         lds_barrier();
