@@ -120,7 +120,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   static_assert(!PPX || (TALL && WM1 == 2 && WN1 == 4 && CH == 0 && !ASYM && OCC == 1), "ping-pong: the 2 x 4 wave layouts of the tall tiles");
   constexpr int RING = (ES == 2 ? 24 : 12) * (CO == 256 ? 2 : 3) / 3 / (OCC * NW > 8 ? OCC : 1);   // fewer fragments in flight for the widest block / at 2 WGs per CU (VGPR budget)
 
-  const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
+  // (DHW_UNIFORM_WAVE: the wave index as a scalar — `wave < 6` of the 192-channel blocks, whose layouts leave two waves without channels, is then a
+  // scalar branch instead of an exec mask)
+  const int tid = body_tid(), lane = tid & 63, wave = DHW_UNIFORM_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int Cin = SK ? CIN : p.Cin;
   // ping-pong: the upper row half (waves NW/2 ..) leads by one phase; a scalar, so the skew barriers sit in scalar branches
@@ -139,9 +141,13 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   // idle waves only join the barriers / copies.  When a layout uses all NW waves the flag must FOLD to true: a run-time
   // `if (act)` around a stage whose loads are consumed inside it leaves, on the (never taken) skip path, loads that were
   // never waited for, and hipcc's s_waitcnt merge at the join then drains the next stage's weight prefetch (r2, .s).
-  const bool act1 = WM1 * WN1 == NW || wave < WM1 * WN1, act2 = WM2 * WN2 == NW || wave < WM2 * WN2;
-  const int wm1 = act1 ? wave / WN1 : 0, wn1 = act1 ? wave % WN1 : 0, row01 = wm1 * (BM1 / WM1), nt01 = wn1 * NT1;
-  const int wm2 = act2 ? wave / WN2 : 0, wn2 = act2 ? wave % WN2 : 0, row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
+  // DHW_CONV_DUP (round 5; gemm_core.h): in the 192-channel blocks (6 channel groups on 8 waves) the two spare waves REPEAT waves 0, 1 — the same tiles,
+  // the same values to the same LDS addresses — so that the flags fold here too: behind a run-time `if (act)` hipcc drained the weight ring in front of
+  // every main loop of these blocks (s_waitcnt vmcnt(2) / (1) / (0) behind their barriers, vmcnt(11 .. 21) in the other blocks).
+  constexpr bool DUP1 = DHW_CONV_DUP != 0 && ES == 2 && NW == 8 && WM1 == 1 && WN1 < NW, DUP2 = DHW_CONV_DUP != 0 && ES == 2 && NW == 8 && WM2 == 1 && WN2 < NW;
+  const bool act1 = DUP1 ? true : (WM1 * WN1 == NW || wave < WM1 * WN1), act2 = DUP2 ? true : (WM2 * WN2 == NW || wave < WM2 * WN2);
+  const int wm1 = DUP1 ? 0 : (act1 ? wave / WN1 : 0), wn1 = DUP1 ? wave % WN1 : (act1 ? wave % WN1 : 0), row01 = wm1 * (BM1 / WM1), nt01 = wn1 * NT1;
+  const int wm2 = DUP2 ? 0 : (act2 ? wave / WN2 : 0), wn2 = DUP2 ? wave % WN2 : (act2 ? wave % WN2 : 0), row02 = wm2 * (BM / WM2), nt02 = wn2 * NT2;
   const int n1 = nt01 * 16 + 4 * g, n2 = nt02 * 16 + 4 * g;   // this lane's first channel in each layout
   const int KCin = Cin / 32;
 

@@ -28,6 +28,9 @@ __device__ __forceinline__ int body_tid() { int t = threadIdx.x; asm volatile(""
 #else
 __device__ __forceinline__ int body_tid() { return threadIdx.x; }
 #endif
+#ifndef DHW_UNIFORM_WAVE
+#define DHW_UNIFORM_WAVE 1
+#endif
 
 // Diagnostic per-stage time stamps (s_memrealtime -> p.stamps[slot]) exist only in builds with -DDHW_STAMPS (the
 // micro-benchmarks under tools/).  Even behind a run-time `if (p.stamps ...)` the stamp blocks changed the product's code:

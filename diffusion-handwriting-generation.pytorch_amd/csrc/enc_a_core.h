@@ -160,8 +160,13 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   static_assert(NT * WN * 16 == DM, "channel tiles must divide over the waves");
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const bool act = WN * WM == 8 || wave < WN * WM;
-  const int wm = act ? wave / WN : 0, wn = act ? wave % WN : 0;
+  // DHW_ENC_DUP (round 5): where the layout leaves waves without channels (DM = 192: 6 x 2 tiles on 8 waves), the spare waves REPEAT waves 0, 1 — the
+  // same tiles, the same values, written to the same LDS addresses — instead of skipping the stages.  With a run-time `if (act)` around every stage hipcc's
+  // s_waitcnt bookkeeping loses the weight ring at each join and drains it in front of every main loop (vmcnt(2) / (1) / (0) behind the barriers of the
+  // d = 192 kernels where the others wait vmcnt(15 .. 26)); with `act` folded away the code is the straight line of the 8-wave layouts.
+  constexpr bool DUP = DHW_ENC_DUP != 0 && sizeof(T) == 2 && WM == 1 && WN < 8;
+  const bool act = DUP ? true : (WN * WM == 8 || wave < WN * WM);   // (DM = 192, 6 x 1 without DUP: waves 6, 7 own no channels in the GEMM stages)
+  const int wm = DUP ? 0 : (act ? wave / WN : 0), wn = DUP ? wave % WN : (act ? wave % WN : 0);
   const int S = tile_stride<T>(DM);
   char* XR = m.XR;
   char* QR = m.QR;
@@ -391,6 +396,9 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[i][j] = acc[i][j] * ep.gam[i] + ep.bet[i] + load4(reinterpret_cast<const T*>(XR + (row0 + j * 16 + l15) * S) + n0 + 16 * i);
+      // (DUP: the spare waves repeat waves 0, 1 — this is the one stage that updates a tile IN PLACE, so every wave's reads of x come before any
+      // wave's stores of x2)
+      if constexpr (DUP) lds_barrier();
       enc_store_tiles<T, NT, MT>(lane, XR, S, row0, n0, acc);
     }
   }

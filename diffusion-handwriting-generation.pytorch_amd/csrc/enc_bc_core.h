@@ -104,8 +104,13 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   constexpr int RING = sizeof(T) == 4 ? 12 : (XS ? XDE * NT : (DM == 384 ? (BM >= 32 ? 15 : DHW_RING384) : (DM == 192 && NT == 3 && BM == 64 ? DHW_RING192 : 24))), RDMAX = XS ? XDE : (RING + NT - 1) / NT;   // (d = 384, 32 rows: two accumulator rows, 24 fragments spill; d = 192 as 4 waves x 3 tiles on 64 rows: the whole stage, 6 chunks — 8 slots spill)
   const int tid = body_tid(), lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const bool act = WN * WM == 8 || wave < WN * WM;   // (DM = 192, 6 x 1: waves 6, 7 own no channels in the GEMM stages)
-  const int wm = act ? wave / WN : 0, wn = act ? wave % WN : 0;
+  // DHW_ENC_DUP (round 5): where the layout leaves waves without channels (DM = 192: 6 x 2 tiles on 8 waves), the spare waves REPEAT waves 0, 1 — the
+  // same tiles, the same values, written to the same LDS addresses — instead of skipping the stages.  With a run-time `if (act)` around every stage hipcc's
+  // s_waitcnt bookkeeping loses the weight ring at each join and drains it in front of every main loop (vmcnt(2) / (1) / (0) behind the barriers of the
+  // d = 192 kernels where the others wait vmcnt(15 .. 26)); with `act` folded away the code is the straight line of the 8-wave layouts.
+  constexpr bool DUP = DHW_ENC_DUP != 0 && sizeof(T) == 2 && WM == 1 && WN < 8;
+  const bool act = DUP ? true : (WN * WM == 8 || wave < WN * WM);   // (DM = 192, 6 x 1 without DUP: waves 6, 7 own no channels in the GEMM stages)
+  const int wm = DUP ? 0 : (act ? wave / WN : 0), wn = DUP ? wave % WN : (act ? wave % WN : 0);
   const int S = tile_stride<T>(DM);
   char* R1 = smem;               // a2, later SiLU(x3)
   char* R2 = R1 + BM * S;        // x3

@@ -152,6 +152,12 @@ struct WRing {
 #ifndef DHW_APF
 #define DHW_APF 3
 #endif
+#ifndef DHW_ENC_DUP
+#define DHW_ENC_DUP 0   // enc_a_core.h / enc_bc_core.h: spare waves repeat waves 0, 1 instead of idling
+#endif
+#ifndef DHW_CONV_DUP
+#define DHW_CONV_DUP 0   // convblock_core.h: the same in the 192-channel blocks
+#endif
 #ifndef DHW_WM192
 #define DHW_WM192 1   // row groups of the d = 192 layout (experiment: 2 with DHW_WN192=4: 2 x 4 waves of 3 channel tiles x half the rows, weights fetched twice)
 #endif
