@@ -109,6 +109,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   static_assert(!ASYM || WM1 == 1, "the asymmetric tiling: blocks with one row group in conv1");
+#ifndef DHW_CONV_STROKES_ONCE
+#define DHW_CONV_STROKES_ONCE 1
+#endif
 #ifndef DHW_CONV_FCX
 #define DHW_CONV_FCX 1
 #endif
@@ -247,8 +250,41 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       store_tiles<T, NTU, MTG>(lane, XS, SX, rowu0, nu, acc, keep, valid);
     }
     STAMP(12);
+  } else if (p.strokes && SK && DHW_CONV_STROKES_ONCE && NTHR % (CIN / 4 > 0 ? CIN / 4 : 1) == 0) {
+    // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load.  A thread's 4 channels are the same in every pass over
+    // the rows (the thread count is a multiple of the items per row), so its 12 weights / biases are requested ONCE and the stroke points of all its
+    // rows up front: the loop below then holds no load at all.  (As one loop of load - compute - store per item — the form below — the stage was
+    // 8-9 dependent memory round trips: 2.0 of enc1's 14.3 us, tools/bench_conv stage0.)
+    constexpr int CPR = CIN / 4 > 0 ? CIN / 4 : 1, IT = (RX * CPR + NTHR - 1) / NTHR, RSTEP = NTHR / CPR;
+    const int c = (tid % CPR) * 4, r0 = tid / CPR;
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(p.in_w + c * 2), wb = *reinterpret_cast<const f32x4*>(p.in_w + c * 2 + 4);   // (w[c][0], w[c][1], w[c+1][0], ..)
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.in_b + c);
+    float2 sp[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int lrow = min(max(m0 - 2 + r0 + it * RSTEP, 0), p.L - 1);
+      sp[it] = *reinterpret_cast<const float2*>(p.strokes + (size_t)(b * p.L + lrow) * 2);
+    }
+    const float w0[4] = {wa[0], wa[2], wb[0], wb[2]}, w1[4] = {wa[1], wa[3], wb[1], wb[3]};
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = r0 + it * RSTEP, lrow = m0 - 2 + r;
+      if (r < RX) {
+        const bool in = lrow >= 0 && lrow < p.L;
+        const float s0 = sp[it].x, s1 = sp[it].y;
+        f32x4 v, sv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t = to_f(from_f<T>(w0[k] * s0 + w1[k] * s1 + bb[k]));
+          v[k] = in ? t : 0.f;
+          sv[k] = in ? CB_SILU(t) : 0.f;
+        }
+        store4(reinterpret_cast<T*>(XR + r * SX) + c, v);
+        store4(reinterpret_cast<T*>(XS + r * SX) + c, sv);
+      }
+    }
   } else if (p.strokes) {
-    // enc1: x = input_dense(strokes) = W[:,0]*dx + W[:,1]*dy + b, evaluated in place of a load
+    // (run-time widths: one item at a time)
     const int cpr = Cin / 4;   // 4 channels per item
     for (int id = tid; id < RX * cpr; id += NTHR) {
       const int r = id / cpr, c = (id - r * cpr) * 4;
