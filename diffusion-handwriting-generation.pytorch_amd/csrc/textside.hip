@@ -369,20 +369,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4 / PAIRS, 
     const T* src = reinterpret_cast<const T*>(p.text_out) + (size_t)pair * p.Lt * DI;
     constexpr int cpr = DI * ES / 16, NU = BM * cpr / 512;
     static_assert(BM * cpr % 512 == 0, "staging chunks per thread");
+    // every piece is requested at a clamped, always valid address and zeroed by a select: written `if (row exists) v = *p` each load was a branch
+    // with s_waitcnt vmcnt(0) at its join — SIX dependent memory round trips at the top of every workgroup (round 5, .s: vmcnt(0) after each of 6 loads)
     uint4 v[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr, pr = r >> 5, rr = r & 31;
-      v[u] = make_uint4(0, 0, 0, 0);
-      if (pr < npair && rr < p.Lt) v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)pr * p.Lt + rr) * DI + cc * (16 / ES));
+      const bool ok = pr < npair && rr < p.Lt;
+      v[u] = *reinterpret_cast<const uint4*>(src + (ok ? (size_t)pr * p.Lt + rr : (size_t)0) * DI + cc * (16 / ES));
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr;
+      const int id = tid + u * 512, r = id / cpr, cc = id - r * cpr, pr = r >> 5, rr = r & 31;
+      const bool ok = pr < npair && rr < p.Lt;
       T* e = reinterpret_cast<T*>(&v[u]);
 #pragma unroll
       for (int i = 0; i < 16 / ES; ++i) e[i] = from_f<T>(silu_t<T>(to_f(e[i])));
-      *reinterpret_cast<uint4*>(XS + r * SI + cc * 16) = v[u];
+      *reinterpret_cast<uint4*>(XS + r * SI + cc * 16) = ok ? v[u] : make_uint4(0, 0, 0, 0);
     }
   }
   if (act) {
