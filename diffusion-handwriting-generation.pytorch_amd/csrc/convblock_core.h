@@ -466,6 +466,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       if (r < rows_valid) {
         const float* xr = reinterpret_cast<const float*>(smem + r * SO);
+        // (unrolled: the 3 x CO / 16 weight pieces are requested together — rolled, every pass waited for its own three loads: CO / 16 dependent
+        // round trips in the tail of the step's last kernel)
+#pragma unroll
         for (int c = q * 4; c < CO; c += 16) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
           const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.hp.w_out + c);
