@@ -109,6 +109,9 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
   constexpr int MT2 = BM / WM2 / 16, NT2 = T2 / WN2;
   static_assert(NT1 * WN1 == T1 && NT2 * WN2 == T2 && MT1 * 16 * WM1 == BM1 && WM1 * WN1 <= NW && WM2 * WN2 <= NW, "unsupported tile / wave layout");
   static_assert(!ASYM || WM1 == 1, "the asymmetric tiling: blocks with one row group in conv1");
+#ifndef DHW_HEADS_PRE
+#define DHW_HEADS_PRE 0   // measured neutral (18.120 vs 18.086 ms on a noisy box, profiles/r05_spread_ab.log r5av): off
+#endif
 #ifndef DHW_CONV_STROKES_ONCE
 #define DHW_CONV_STROKES_ONCE 1
 #endif
@@ -464,6 +467,11 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
       // eps / pen heads (model.py:179-182) + scheduler step straight from the fp32 tile: 4 lanes per stroke row
       const int r = tid >> 2, q = tid & 3;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      // (DHW_HEADS_PRE: what the scheduler step reads — biases, seed, sampler state, noise — requested, and the Philox draw computed, in front of the
+      // dot products; rows past the tile read row m0's)
+      const long hrow = (long)b * p.L + m0 + (r < rows_valid ? r : 0);
+      HeadsPre hpre;
+      if constexpr (DHW_HEADS_PRE != 0) heads_prefetch(p.hp, hrow, hpre);
       if (r < rows_valid) {
         const float* xr = reinterpret_cast<const float*>(smem + r * SO);
         // (unrolled: the 3 x CO / 16 weight pieces are requested together — rolled, every pass waited for its own three loads: CO / 16 dependent
@@ -484,7 +492,10 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
         a1 += __shfl_xor(a1, o);
         a2 += __shfl_xor(a2, o);
       }
-      if (r < rows_valid && q == 0) heads_finish(p.hp, (long)b * p.L + m0 + r, a0, a1, a2);
+      if (r < rows_valid && q == 0) {
+        if constexpr (DHW_HEADS_PRE != 0) heads_finish_pre(p.hp, hrow, a0, a1, a2, hpre);
+        else heads_finish(p.hp, (long)b * p.L + m0 + r, a0, a1, a2);
+      }
     }
   } else {
     if (act2) {

@@ -32,6 +32,50 @@ DHW_DEV void normal2(uint64_t seed, int64_t sample, int pos, int iter, float& z0
   z1 = rad * sn;
 }
 
+// What heads_finish reads from memory for one stroke row, requested AHEAD of the dot products (the dec1 ConvBlock kernel: its tail was a chain of
+// dependent round trips — biases, then the seed, then the sampler state — at the end of every step's last launch).  Every load is unconditional, at a
+// valid address: a field the configuration does not have (no scheduler step, external noise) is read from the bias vector instead and never used.
+struct HeadsPre {
+  float b0, b1, bp, x0, x1, z0, z1;
+};
+template <typename HP>
+DHW_DEV void heads_prefetch(const HP& p, long row, HeadsPre& h) {
+  const float* bo = p.b_out;
+  const float* xs = p.xt ? p.xt + row * 2 : bo;
+  const float* zs = p.z ? p.z + row * 2 : bo;
+  const uint64_t* sp = p.seed_ptr ? p.seed_ptr : reinterpret_cast<const uint64_t*>(p.w_out);   // (16 valid bytes either way)
+  const uint64_t s0 = sp[0], s1 = sp[1];
+  h.b0 = bo[0]; h.b1 = bo[1]; h.bp = p.b_pen[0];
+  h.x0 = xs[0]; h.x1 = xs[1];
+  h.z0 = zs[0]; h.z1 = zs[1];
+  if (p.xt && p.add_noise && !p.z)   // (uniform; arithmetic only: the draw runs while the heads' weight pieces are in flight)
+    normal2(s0, (int64_t)s1 + p.sample_off + row / p.L, (int)(row % p.L), p.iter, h.z0, h.z1);
+}
+// heads_finish on prefetched inputs: the same operations in the same order
+template <typename HP>
+DHW_DEV void heads_finish_pre(const HP& p, long row, float a0, float a1, float a2, const HeadsPre& h) {
+  const float e0 = a0 + h.b0, e1 = a1 + h.b1;
+  const float pen = 1.0f / (1.0f + expf(-(a2 + h.bp)));
+  if (p.eps) { p.eps[row * 2] = e0; p.eps[row * 2 + 1] = e1; }
+  if (p.pen) p.pen[row] = pen;
+  if (p.xt) {
+    const float z0 = p.add_noise ? h.z0 : 0.f, z1 = p.add_noise ? h.z1 : 0.f;
+    float x0 = h.x0, x1 = h.x1;
+    if (p.mode == 0) {
+      x0 = __fdiv_rn(__fsub_rn(x0, __fmul_rn(p.k0, e0)), p.k1);
+      x1 = __fdiv_rn(__fsub_rn(x1, __fmul_rn(p.k0, e1)), p.k1);
+      if (p.add_noise) { x0 = __fadd_rn(x0, __fmul_rn(z0, p.k2)); x1 = __fadd_rn(x1, __fmul_rn(z1, p.k2)); }
+    } else {
+      x0 = __fmul_rn(p.k1, __fsub_rn(x0, __fdiv_rn(__fmul_rn(p.k3, e0), p.k0)));
+      x1 = __fmul_rn(p.k1, __fsub_rn(x1, __fdiv_rn(__fmul_rn(p.k3, e1), p.k0)));
+      if (p.add_noise) { x0 = __fadd_rn(x0, __fmul_rn(p.k2, z0)); x1 = __fadd_rn(x1, __fmul_rn(p.k2, z1)); }
+    }
+    p.xt[row * 2] = x0;
+    p.xt[row * 2 + 1] = x1;
+    if (p.out3) { p.out3[row * 3] = x0; p.out3[row * 3 + 1] = x1; p.out3[row * 3 + 2] = pen; }
+  }
+}
+
 // a0, a1: eps dot products (without bias); a2: pen-lift logit (without bias); row: global stroke row
 // (HP: HeadsParams, or the same struct in the constant address space when the caller's parameters live in a plan in memory)
 template <typename HP>
