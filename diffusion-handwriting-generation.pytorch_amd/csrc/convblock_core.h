@@ -507,7 +507,8 @@ DHW_DEV void convblock_body(const P& p, const X& nx, const int b, const int m0, 
     }
     CB_BARRIER();
     if constexpr (PPX) { if (pp_lead) CB_BARRIER(); }   // the trailing half stores its rows one slot later
-    if constexpr (!(DHW_ABL & 16))
+    if constexpr (DHW_COPY_UNROLL != 0 && !(DHW_ABL & 16)) tile_copy_out_u<T, BM, CO, NTHR>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, tid);
+    else if constexpr (!(DHW_ABL & 16))
     tile_copy_out<T>(smem, SH2, reinterpret_cast<T*>(p.out) + (size_t)(b * p.L + m0) * CO, CO, rows_valid, CO, tid, NTHR);
     if (p.pool && !(DHW_ABL & 16))   // AvgPool1d(2) side output (model.py:93); m0 and rows_valid are even
       tile_copy_out_pool<T>(smem, SH2, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.L / 2) + m0 / 2) * CO, CO, rows_valid, CO, tid, NTHR);

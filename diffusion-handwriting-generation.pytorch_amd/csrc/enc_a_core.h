@@ -404,7 +404,8 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
   }
   lds_barrier();
   ENC_STAMP(4);
-  tile_copy_out<T>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
+  if constexpr (DHW_COPY_UNROLL != 0) tile_copy_out_u<T, BM, DM, 512>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, tid);
+  else tile_copy_out<T>(XR, S, reinterpret_cast<T*>(p.x2) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
 
   // ---- [q2 | k2 | v2] = W x2 + b (+ PE·W for q, k), one DM-wide chunk at a time.  The opaque zero keeps hipcc
   // from treating the x2 fragment reads / store addresses as chunk-invariant and hoisting (then spilling) them.
@@ -481,7 +482,8 @@ DHW_DEV void enc_a_body(const P& p, const EncALds& m, int b, int m0, int rows_va
         if constexpr (SPREADQ) { if (chunk < 2) ring.template fill_range<KC, 2 * FQA, 3 * FQA>(); }
       }
       lds_barrier();
-      tile_copy_out<T>(QT, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);
+      if constexpr (DHW_COPY_UNROLL != 0) tile_copy_out_u<T, BM, DM, 512>(QT, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, tid);
+      else tile_copy_out<T>(QT, S, reinterpret_cast<T*>(p.qk2) + (size_t)(b * p.Lk + m0) * QKS + chunk * DM, QKS, rows_valid, DM, tid, 512);
       if constexpr (SPREADQ) { if (act && chunk < 2) ring.template fill_range<KC, 3 * FQA, FCHA>(); }
     } else if constexpr (!VROW) {
       // v2 chunk -> LDS tile [channel][key] (key-contiguous, zero past the valid rows) -> coalesced rows of vt2

@@ -445,7 +445,8 @@ DHW_DEV void enc_bc_body(const P& p, const X& nx, const int b, const int m0, cha
   }
   lds_barrier();
   const int rows_valid = min(BM, p.Lk - m0);
-  tile_copy_out<T>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
+  if constexpr (DHW_COPY_UNROLL != 0) tile_copy_out_u<T, BM, DM, 512>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, tid);
+  else tile_copy_out<T>(R3, S, reinterpret_cast<T*>(p.out) + (size_t)(b * p.Lk + m0) * DM, DM, rows_valid, DM, tid, 512);
   if (p.pool)
     tile_copy_out_pool<T>(R3, S, reinterpret_cast<T*>(p.pool) + ((size_t)b * (p.Lk / 2) + m0 / 2) * DM, DM, rows_valid, DM, tid, 512);
   STAMP(24);

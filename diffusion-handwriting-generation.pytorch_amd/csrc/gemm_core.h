@@ -366,6 +366,30 @@ DHW_DEV void mainloop(f32x4 (&acc)[NT][MT], const T* __restrict__ wbase, const c
 // `gs` elements): 16 bytes per lane, consecutive lanes on consecutive addresses.  Per-lane 8-byte stores straight from
 // the MFMA accumulators touch 16 rows per instruction and are store-issue bound (measured 5 us for a 64x384 tile vs
 // <1 us through LDS).
+// The same with the trip count known (ROWS = rows of the tile, CC = its channels, NTH threads): every piece is read from LDS BEFORE the first store, so
+// a thread pays the LDS latency once per tile instead of once per piece (the rolled loop below is read - wait - store per pass).  DHW_COPY_UNROLL.
+// MEASURED SLOWER: 17.539 vs 17.428 ms same-box (profiles/r05_spread_ab.log, r5aw) — the rolled loop's stores start behind the first read, and the
+// per-piece `if (id < total)` of the unrolled form is a join per store.  Off.
+#ifndef DHW_COPY_UNROLL
+#define DHW_COPY_UNROLL 0
+#endif
+template <typename T, int ROWS, int CC, int NTH>
+DHW_DEV void tile_copy_out_u(const char* lds, int S, T* gdst, int gs, int rows_valid, int tid) {
+  constexpr int ES = sizeof(T), EPV = 16 / ES, CPR = CC / EPV, IT = (ROWS * CPR + NTH - 1) / NTH;
+  const int total = rows_valid * CPR;
+  uint4 v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int id = min(tid + it * NTH, ROWS * CPR - 1), r = id / CPR, cc = id - r * CPR;   // (clamped: inside the tile)
+    v[it] = *reinterpret_cast<const uint4*>(lds + r * S + cc * 16);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int id = tid + it * NTH, r = id / CPR, cc = id - r * CPR;
+    if (id < total) *reinterpret_cast<uint4*>(gdst + (size_t)r * gs + cc * EPV) = v[it];
+  }
+}
+
 template <typename T>
 DHW_DEV void tile_copy_out(const char* lds, int S, T* gdst, int gs, int rows_valid, int C, int tid, int nthreads) {
   constexpr int ES = sizeof(T), EPV = 16 / ES;
