@@ -476,15 +476,17 @@ DHW_DEV void attn_stage_kv(char* kt, int SK, char* vt, int SV, const T* ksrc, in
                            int kb, int kmax, int tid, int nthreads) {
   constexpr int ES = sizeof(T), EPV = 16 / ES, PPR = KB / EPV;
   const int cpr = C / EPV;            // 16-byte pieces per K row; PPR = pieces per V^T row
-  staged_copy<6>(KB * cpr, tid, nthreads,
+  staged_copy_clamped<6>(KB * cpr, tid, nthreads,
       [&](int id) { const int r = id / cpr, cc = id - r * cpr;
-                    return kb + r < kmax ? reinterpret_cast<const uint4*>(ksrc + (size_t)(kb + r) * ldk + cc * EPV) : nullptr; },
+                    return reinterpret_cast<const uint4*>(ksrc + (size_t)min(kb + r, kmax - 1) * ldk + cc * EPV); },
+      [&](int id) { return kb + id / cpr < kmax; },
       [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(kt + r * SK + cc * 16); });
   if constexpr (sizeof(T) == 2) {
     // V rows [kb, kb + KB) x C channels, row stride `lpad` ELEMENTS here (the caller's V row stride), zero past kmax
-    staged_copy<6>(KB * cpr, tid, nthreads,
+    staged_copy_clamped<6>(KB * cpr, tid, nthreads,
         [&](int id) { const int r = id / cpr, cc = id - r * cpr;
-                      return kb + r < kmax ? reinterpret_cast<const uint4*>(vsrc + (size_t)(kb + r) * lpad + cc * EPV) : nullptr; },
+                      return reinterpret_cast<const uint4*>(vsrc + (size_t)min(kb + r, kmax - 1) * lpad + cc * EPV); },
+        [&](int id) { return kb + id / cpr < kmax; },
         [&](int id) { const int r = id / cpr, cc = id - r * cpr; return reinterpret_cast<uint4*>(vt + r * SV + cc * 16); });
   } else {
     constexpr int U = 6;

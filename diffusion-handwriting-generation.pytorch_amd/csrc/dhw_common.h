@@ -144,6 +144,26 @@ DHW_DEV void staged_copy(int total, int tid, int nthreads, SrcF src, DstF dst) {
   }
 }
 
+// The same with src(id) ALWAYS a valid address (the caller clamps the row) and keep(id) saying whether the piece is real or reads as zero: no branch
+// around a load, so the U requests of a pass really are in flight together (the null-pointer form above compiles to one branch per piece with
+// s_waitcnt vmcnt(0) at its join — U dependent round trips per pass: round 5, .s of the text-key blocks behind the first).
+template <int U, typename SrcF, typename KeepF, typename DstF>
+DHW_DEV void staged_copy_clamped(int total, int tid, int nthreads, SrcF src, KeepF keep, DstF dst) {
+  for (int base = tid; base < total; base += nthreads * U) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = min(base + u * nthreads, total - 1);
+      v[u] = *src(id);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = base + u * nthreads;
+      if (id < total) *dst(id) = keep(id) ? v[u] : make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
 // The same copy split in two: load() requests this thread's <= U pieces, store() writes them to LDS.  Several tiles staged
 // by one workgroup issue ALL their loads before the first store, so they cost one memory round trip together instead
 // of one each (enc_a staged x, then the text keys, then the text values: three dependent L2 / HBM latencies).
