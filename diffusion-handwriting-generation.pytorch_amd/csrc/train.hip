@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, flo
     const long n4 = n / 4;
     f32x4 a = (f32x4){0, 0, 0, 0}, b = a;
     long i = t;
+    // (round 5: eight requests in flight per pass and 512 workgroups — 2048 workgroups x two requests took 32 us for the 40 MB gradient buffer:
+    // five dependent round trips per thread and 2048 atomics on one address)
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+      f32x4 u[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = g4[i + k * stride];
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) { a += u[k] * u[k]; b += u[k + 1] * u[k + 1]; }
+    }
     for (; i + stride < n4; i += 2 * stride) {
       const f32x4 u = g4[i], v = g4[i + stride];
       a += u * u;
@@ -311,7 +320,7 @@ hipError_t launch_loss(const float* eps, const float* pred, const float* pen, co
   return hipGetLastError();
 }
 hipError_t launch_sqnorm(const float* g, long n, float* out, hipStream_t st) {   // out must be zeroed by the caller (several buffers add up)
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(std::min<unsigned>(nb(n), 2048u)), dim3(256), 0, st, g, n, out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(std::min<unsigned>(nb(n), 512u)), dim3(256), 0, st, g, n, out);
   return hipGetLastError();
 }
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
