@@ -1433,11 +1433,28 @@ __global__ __launch_bounds__(256) void film_table_wgrad_kernel(const float* dfil
   for (int b0 = 0; b0 < B; b0 += 32) {
     const int nb_ = min(32, B - b0);
     __syncthreads();
-    for (int e = t; e < 32 * 64; e += 256) {
-      const int b = e >> 6, c = e & 63;
-      df[b][c] = b < nb_ && j0 + c < TOT ? dfilm[(long)(b0 + b) * TOT + j0 + c] : 0.f;
+    // (unconditional clamped requests, all in flight before the first LDS store: see film_table_dgrad_kernel)
+    float dv[8], sv[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = t + u * 256, b = e >> 6, c = e & 63;
+      dv[u] = dfilm[(long)(b0 + min(b, nb_ - 1)) * TOT + min(j0 + c, TOT - 1)];
     }
-    for (int e = t; e < 32 * 32; e += 256) sg[e >> 5][e & 31] = (e >> 5) < nb_ ? sigma[(b0 + (e >> 5)) * 32 + (e & 31)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + u * 256;
+      sv[u] = sigma[(b0 + min(e >> 5, nb_ - 1)) * 32 + (e & 31)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = t + u * 256, b = e >> 6, c = e & 63;
+      df[b][c] = b < nb_ && j0 + c < TOT ? dv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + u * 256;
+      sg[e >> 5][e & 31] = (e >> 5) < nb_ ? sv[u] : 0.f;
+    }
     __syncthreads();
 #pragma unroll 8
     for (int b = 0; b < 32; ++b) {
@@ -1456,24 +1473,44 @@ __global__ __launch_bounds__(256) void film_table_wgrad_kernel(const float* dfil
 // dsigma[b][k] += sum_j dfilm[b][j] W[j][k]: block = FTD columns for 32 samples; the weight rows of the chunk ([FTD][32]) and the
 // dfilm tile ([32][FTD]) through LDS once, a thread = (sample, 4 of the 32 k), four atomics per thread.  (One block per (sample,
 // chunk) re-read the chunk's weight rows for every sample: 76 MB of L2 reads for a 2.4 MB matrix, 19 us.)
-constexpr int FTD = 64;   // (290 workgroups for the 18 560 columns of num_layers = 2: every CU gets one)
+constexpr int FTD = 64;   // (290 column chunks for the 18 560 columns of num_layers = 2, walked by 64 workgroups)
 __global__ __launch_bounds__(256) void film_table_dgrad_kernel(const float* dfilm, const float* flat, const int64_t* woff, int B, int TOT, float* dsigma) {
   __shared__ __attribute__((aligned(16))) float W[FTD][36];
   __shared__ float df[32][FTD + 1];
-  const int t = threadIdx.x, j0 = blockIdx.x * FTD, nj = min(FTD, TOT - j0), b0 = blockIdx.y * 32, nb_ = min(32, B - b0);
-  for (int e = t; e < FTD * 8; e += 256) {
-    const int c = e >> 3, k4 = e & 7;
-    *reinterpret_cast<f32x4*>(&W[c][4 * k4]) = c < nj ? *reinterpret_cast<const f32x4*>(flat + woff[j0 + c] + 4 * k4) : (f32x4){0, 0, 0, 0};
-  }
-  for (int e = t; e < 32 * FTD; e += 256) {
-    const int b = e / FTD, c = e - b * FTD;
-    df[b][c] = b < nb_ && c < nj ? dfilm[(long)(b0 + b) * TOT + j0 + c] : 0.f;
-  }
-  __syncthreads();
+  const int t = threadIdx.x, b0 = blockIdx.y * 32, nb_ = min(32, B - b0);
   const int b = t >> 3, kq = t & 7;
   f32x4 s = (f32x4){0, 0, 0, 0};
+  // (round 5: a workgroup walks over several column chunks and adds its 1 024 partial sums to dsigma ONCE — 290 workgroups x 1 024 atomics on the same
+  // 1 024 addresses were 25 of the kernel's 31 us; every request unconditional at a clamped address, all of a pass in flight before its first LDS store)
+  for (int j0 = blockIdx.x * FTD; j0 < TOT; j0 += gridDim.x * FTD) {
+    const int nj = min(FTD, TOT - j0);
+    int64_t wo[FTD * 8 / 256];
+#pragma unroll
+    for (int u = 0; u < FTD * 8 / 256; ++u) wo[u] = woff[j0 + min((t + u * 256) >> 3, nj - 1)];
+    float dv[32 * FTD / 256];
+#pragma unroll
+    for (int u = 0; u < 32 * FTD / 256; ++u) {
+      const int e = t + u * 256, bb = e / FTD, c = e - bb * FTD;
+      dv[u] = dfilm[(long)(b0 + min(bb, nb_ - 1)) * TOT + j0 + min(c, nj - 1)];
+    }
+    f32x4 wv[FTD * 8 / 256];
+#pragma unroll
+    for (int u = 0; u < FTD * 8 / 256; ++u) wv[u] = *reinterpret_cast<const f32x4*>(flat + wo[u] + 4 * ((t + u * 256) & 7));
+    __syncthreads();   // (the previous chunk's tiles have been read)
+#pragma unroll
+    for (int u = 0; u < 32 * FTD / 256; ++u) {
+      const int e = t + u * 256, bb = e / FTD, c = e - bb * FTD;
+      df[bb][c] = bb < nb_ && c < nj ? dv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < FTD * 8 / 256; ++u) {
+      const int e = t + u * 256, c = e >> 3, k4 = e & 7;
+      *reinterpret_cast<f32x4*>(&W[c][4 * k4]) = c < nj ? wv[u] : (f32x4){0, 0, 0, 0};
+    }
+    __syncthreads();
 #pragma unroll 8
-  for (int c = 0; c < FTD; ++c) s += df[b][c] * *reinterpret_cast<const f32x4*>(&W[c][4 * kq]);
+    for (int c = 0; c < FTD; ++c) s += df[b][c] * *reinterpret_cast<const f32x4*>(&W[c][4 * kq]);
+  }
   if (b < nb_) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) atomicAdd(dsigma + (b0 + b) * 32 + 4 * kq + k, s[k]);
@@ -1488,7 +1525,7 @@ hipError_t launch_film_table(int dir, const float* sigma, const float* flat, con
     hipLaunchKernelGGL(film_table_fwd_kernel, dim3(nb(TOT, 64), nb(B, FTB)), dim3(64), 0, st, sigma, flat, woff, boff, B, TOT, film);
   } else {
     hipLaunchKernelGGL(film_table_wgrad_kernel, dim3(nb(TOT, 64)), dim3(256), 0, st, film, sigma, woff, boff, B, TOT, gflat);
-    hipLaunchKernelGGL(film_table_dgrad_kernel, dim3(nb(TOT, FTD), nb(B, 32)), dim3(256), 0, st, film, flat, woff, B, TOT, dsigma);
+    hipLaunchKernelGGL(film_table_dgrad_kernel, dim3(std::min<unsigned>(nb(TOT, FTD), 64u), nb(B, 32)), dim3(256), 0, st, film, flat, woff, B, TOT, dsigma);
   }
   return hipGetLastError();
 }
